@@ -1,0 +1,174 @@
+"""Generate tests/golden/*.npz from the imported reference (build container only).
+
+    python -m oracle.gen_golden            # from the repo root
+
+Each fixture is DATA: the scripted inputs (ops, actions, sort modes, flags) and what the
+reference returned / held after every op (obs f32, reward f64, terminated, action mask, integer
+state, accuracy doubles, PCG64 states of the three live streams).  Nothing of the reference's
+source is stored.  Layout of the integer snapshot: oracle/oracle.py SNAP.
+
+Row ops:  op=0  step(action[, sort_mode], flags)      op=1  reset(seed=arg)
+"""
+from __future__ import annotations
+
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from oracle import ref_harness  # noqa: E402
+from oracle.oracle import STEP_CHECK_OVERFLOW, STEP_UNMASKED  # noqa: E402
+
+OUT_DIR = os.path.join(ROOT, "tests", "golden")
+
+POLICIES = ("masked_uniform", "noop", "wrong_mode", "ignore_mask_uniform", "greedy_press")
+
+
+def scenarios():
+    """(name, kind, ctor kwargs, seeds for the reset boundaries, policy, masking, check_overflow, steps/segment)"""
+    S = []
+    big = (1 << 32) - 3  # seed+3/+4/+99 need two SeedSequence words; the reference caps seeds at 2**32-1 (np.random.seed)
+    for kind in ("mono", "press", "sort"):
+        for noise in (0.0, 0.05):
+            ntag = "n0" if noise == 0.0 else "n5"
+            S.append((f"{kind}_{ntag}_masked_s0_s3", kind, dict(max_steps=200, noise_sorting=noise, balesize=200),
+                      [0, 3], "masked_uniform", True, False, 215))
+            S.append((f"{kind}_{ntag}_masked_s1_s42", kind, dict(max_steps=200, noise_sorting=noise, balesize=200),
+                      [1, 42], "masked_uniform", True, False, 215))
+            S.append((f"{kind}_{ntag}_ignoremask_on_s42_s7", kind, dict(max_steps=200, noise_sorting=noise, balesize=200),
+                      [42, 7], "ignore_mask_uniform", True, False, 205))
+            if kind != "sort":
+                S.append((f"{kind}_{ntag}_unmasked_s3_s{big}", kind, dict(max_steps=200, noise_sorting=noise, balesize=200),
+                          [3, big], "ignore_mask_uniform", False, False, 205))
+        S.append((f"{kind}_n0_noop_s3", kind, dict(max_steps=200, noise_sorting=0.0, balesize=200),
+                  [3], "noop", True, False, 200))
+        S.append((f"{kind}_n0_wrongmode_s0", kind, dict(max_steps=200, noise_sorting=0.0, balesize=200),
+                  [0, 123456789], "wrong_mode", True, False, 120))
+        S.append((f"{kind}_n5_overflow_s1", kind, dict(max_steps=200, noise_sorting=0.05, balesize=200),
+                  [1, 2], "noop", True, True, 90))
+        S.append((f"{kind}_n5_greedy_s5_bale150_T50", kind, dict(max_steps=50, noise_sorting=0.05, balesize=150),
+                  [5, 6, 99991], "greedy_press", True, False, 60))
+    return S
+
+
+def choose(policy, kind, env, prng, t):
+    """Returns (action, sort_mode) for the next step; sort_mode only matters for 'press'."""
+    mask = np.asarray(env.action_masks(), dtype=bool)
+    n_act = mask.size
+    sort_mode = int(prng.integers(0, 2))
+    if policy == "masked_uniform":
+        a = int(prng.choice(np.flatnonzero(mask)))
+    elif policy == "ignore_mask_uniform":
+        a = int(prng.integers(0, n_act))
+    elif policy == "noop":
+        a = 0
+        sort_mode = int((t // 7) % 2)
+        if kind == "sort":
+            a = sort_mode
+        elif kind == "mono":
+            a = 11 * sort_mode
+    elif policy == "wrong_mode":
+        # boost the group that is NOT dominant on the belt
+        belt = env.current_material_belt
+        wrong = 1 if (belt[0] + belt[2]) > (belt[1] + belt[3]) else 0
+        sort_mode = wrong
+        if kind == "sort":
+            a = wrong
+        else:
+            valid = np.flatnonzero(mask[:11]) if kind == "mono" else np.flatnonzero(mask)
+            p = int(prng.choice(valid))
+            a = p + 11 * wrong if kind == "mono" else p
+    elif policy == "greedy_press":
+        # press whenever the mask allows it (highest valid press action), alternate modes
+        sort_mode = int(t % 2)
+        if kind == "sort":
+            a = sort_mode
+        else:
+            valid = np.flatnonzero(mask[:11]) if kind == "mono" else np.flatnonzero(mask)
+            p = int(valid[-1])
+            a = p + 11 * sort_mode if kind == "mono" else p
+    else:
+        raise ValueError(policy)
+    return a, sort_mode
+
+
+def run_scenario(sc):
+    name, kind, kw, seeds, policy, masking, check_overflow, seg = sc
+    classes = ref_harness.load()
+    env = classes[kind](seed=seeds[0], **kw)
+    agent = None
+    if kind == "press":
+        agent = ref_harness.ScriptedSortAgent()
+        env.set_agents(sort_agent=agent)
+    prng = np.random.default_rng(sum(name.encode()) * 7919)  # policy stream, independent of the env
+    D = env.observation_space.shape[0]
+    A = env.action_space.n
+    rows = {k: [] for k in ("op", "arg", "sort_mode", "flags", "obs", "reward", "terminated", "mask",
+                            "ints", "dbls", "rng")}
+
+    def record(op, arg, sm, flags, obs, rew, term):
+        I, Dd, R = ref_harness.snapshot(env)
+        rows["op"].append(op)
+        rows["arg"].append(arg)
+        rows["sort_mode"].append(sm)
+        rows["flags"].append(flags)
+        rows["obs"].append(np.asarray(obs, dtype=np.float32))
+        rows["reward"].append(float(rew))
+        rows["terminated"].append(int(term))
+        rows["mask"].append(np.asarray(env.action_masks(), dtype=np.uint8))
+        rows["ints"].append(I)
+        rows["dbls"].append(Dd)
+        rows["rng"].append(R)
+
+    flags = (0 if masking else STEP_UNMASKED) | (STEP_CHECK_OVERFLOW if check_overflow else 0)
+    for seed in seeds:
+        obs, _ = env.reset(seed=seed)
+        record(1, seed, -1, 0, obs, 0.0, 0)
+        for t in range(seg):
+            a, sm = choose(policy, kind, env, prng, t)
+            kwargs = dict(use_action_masking=masking, check_overflow=check_overflow)
+            if kind == "press":
+                agent.next_mode = sm
+            obs, rew, term, trunc, info = env.step(a, **kwargs)
+            assert trunc is False
+            record(0, a, sm if kind == "press" else -1, flags, obs, rew, term)
+            if term and check_overflow:
+                break  # overflow-terminated: go to the next seeded reset
+    out = {k: np.asarray(v) for k, v in rows.items()}
+    out["op"] = out["op"].astype(np.uint8)
+    out["arg"] = out["arg"].astype(np.uint64)
+    out["sort_mode"] = out["sort_mode"].astype(np.int8)
+    out["flags"] = out["flags"].astype(np.uint8)
+    out["terminated"] = out["terminated"].astype(np.uint8)
+    out["rng"] = out["rng"].astype(np.uint64)
+    assert out["obs"].shape[1] == D and out["mask"].shape[1] == A
+    meta = dict(name=name, kind=kind, max_steps=kw["max_steps"], noise_sorting=kw["noise_sorting"],
+                balesize=kw["balesize"], ctor_seed=int(seeds[0]), policy=policy, masking=bool(masking),
+                check_overflow=bool(check_overflow), numpy=np.__version__,
+                generator="oracle/gen_golden.py from the imported reference")
+    out["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    return name, out
+
+
+def main():
+    if not ref_harness.available():
+        raise SystemExit("reference checkout not available: fixtures can only be generated in the build container")
+    os.makedirs(OUT_DIR, exist_ok=True)
+    total = 0
+    for sc in scenarios():
+        name, out = run_scenario(sc)
+        path = os.path.join(OUT_DIR, name + ".npz")
+        np.savez_compressed(path, **out)
+        sz = os.path.getsize(path)
+        total += sz
+        print(f"{name:48s} rows={len(out['op']):4d}  {sz/1024:7.1f} KiB")
+    print(f"total {total/1024:.1f} KiB")
+
+
+if __name__ == "__main__":
+    main()

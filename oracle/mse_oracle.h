@@ -1,0 +1,151 @@
+/*
+ * mse_oracle.h -- CPU ORACLE for the batched MARL-SortingEnv step() path.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may load it.  The shipped path (marl-sortingenv_amd/)
+ * never links, imports or calls anything in oracle/.
+ *
+ * It is a scalar, one-env-at-a-time restatement in plain C of the reference's algorithm
+ * (all citations are path:line under the reference checkout):
+ *   src/envs_train/env_super.py     Env_Super      (state, flow, sorting, presses, masks, obs, rewards)
+ *   src/envs_train/env_1_sort.py    Env_1_Sorting  step sequencing
+ *   src/envs_train/env_2_press.py   Env_2_Pressing step sequencing
+ *   src/envs_train/env_monolith.py  Env_3_Monolith step sequencing
+ *   utils/input_generator.py:12-64  SeasonalInputGenerator
+ *   config.yml                      numeric constants
+ * plus the third-party arithmetic the path relies on, numpy==2.2.6 (docs/environment_full.yml:154)
+ * numpy.random.Generator / PCG64 / SeedSequence, restated from its published algorithm.
+ *
+ * Parity pin: tests/golden/ (vectors generated from the imported reference by
+ * oracle/gen_golden.py in the build container) and direct comparison with the installed
+ * numpy 2.2.6 for the RNG recipes (tests/test_oracle_rng.py).
+ */
+#ifndef MSE_ORACLE_H
+#define MSE_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- numpy.random restatement -------------------------------------------------------- */
+
+typedef struct {
+    uint64_t state_hi, state_lo; /* 128-bit LCG state                                   */
+    uint64_t inc_hi, inc_lo;     /* 128-bit odd increment                                */
+    int32_t  has_uint32;         /* buffered upper half of the last 64-bit output        */
+    uint32_t uinteger;
+} orc_pcg64;
+
+void     orc_seed_sequence_u64x4(uint64_t entropy, uint64_t out[4]);
+void     orc_pcg64_seed(orc_pcg64 *g, uint64_t seed);          /* np.random.default_rng(seed)  */
+uint64_t orc_pcg64_next64(orc_pcg64 *g);
+uint32_t orc_pcg64_next32(orc_pcg64 *g);
+double   orc_pcg64_random(orc_pcg64 *g);                        /* Generator.random()           */
+double   orc_pcg64_uniform(orc_pcg64 *g, double lo, double hi); /* Generator.uniform(lo, hi)     */
+int64_t  orc_pcg64_integers(orc_pcg64 *g, int64_t lo, int64_t hi_excl); /* Generator.integers  */
+int      orc_pcg64_choice_p(orc_pcg64 *g, const double *p, int n);      /* Generator.choice(n,p) */
+int      orc_permutation12_first(uint64_t seed); /* first element of default_rng(seed).permutation([1,2]) */
+double   orc_round2(double x);                   /* round(np.float64, 2)                         */
+int64_t  orc_rint_i64(double x);                 /* int(round(np.float64))                       */
+
+/* ---- environment --------------------------------------------------------------------- */
+
+enum { ORC_ENV_SORT = 1, ORC_ENV_PRESS = 2, ORC_ENV_MONO = 3 };
+
+/* step flags */
+enum { ORC_STEP_UNMASKED = 1u, ORC_STEP_CHECK_OVERFLOW = 2u };
+
+typedef struct {
+    /* simulation (config.yml:4-9) */
+    int32_t input_occupancy_min, input_occupancy_max, input_batch_size, steps_per_pattern;
+    /* sorting_station (config.yml:12-18) */
+    double  baseline_accuracy[4], boost, noise;
+    int32_t stage_capacity;
+    /* pressing_station (config.yml:21-32) */
+    int32_t press_time[2], container_capacity, bale_standard_size;
+    double  bale_remainder_threshold, quality_threshold[4];
+    /* rewards (config.yml:35-59) */
+    double  purity_threshold_theta, tanh_temperature;
+    double  overflow_penalty_catastrophic, overflow_penalty_severe, overflow_penalty_mild;
+    double  bale_efficiency_factor, max_state_reward, overflow_termination_penalty;
+    /* seasonal patterns, order A,B,C,D (utils/input_generator.py:17-20) */
+    double  pattern_ratio[2][4];
+    /* env ctor args (env_monolith.py:22-23) */
+    int32_t env_kind, max_steps;
+} orc_config;
+
+typedef struct {
+    int64_t size;
+    int32_t q;
+} orc_bale;
+
+typedef struct {
+    orc_config cfg;
+
+    int32_t input[4], belt[4], sorting[4];
+    double  acc_belt[4], acc_sorter[4];
+    int32_t sensor_mode;
+    double  input_occupancy, belt_occupancy;
+    int64_t cont_true[4], cont_false[4], cont_e;
+    int32_t press_timer[2], press_mat[2]; /* press_mat: 0..4 = A..E, -1 idle */
+    int64_t press_n[2];
+    double  press_q[2];
+    int32_t last_press_started;
+    int64_t last_press_amount;
+    int32_t current_step;
+
+    /* generator */
+    int32_t gen_first;   /* pattern key (1|2) at pattern_sequence[0] */
+    int32_t gen_idx, gen_counter;
+
+    /* RNG streams (env_super.py:170-174) */
+    orc_pcg64 rng_input, rng_sorting, rng_pressing, rng_noise, rng;
+
+    /* identity for the build's own unseeded-reset rule (see orc_env_reset) */
+    uint32_t episode;
+
+    /* bale ledger, 5 materials */
+    orc_bale *bales[5];
+    int32_t   n_bales[5], cap_bales[5];
+
+    /* last press ledger entry (press_actions_per_timestep[-1]): code 0 noop, 1|2 press id,
+     * 111|222 invalid/busy, -1 nothing logged this step; material 0..4 or -1 */
+    int32_t last_log_code, last_log_mat;
+    /* Env_1: press action sampled inside the env this step (0..10) */
+    int32_t last_internal_press_action;
+    int64_t draws_this_step;
+} orc_env;
+
+void orc_config_default(orc_config *cfg);
+orc_env *orc_env_create(const orc_config *cfg, int has_seed, uint64_t seed);
+void orc_env_destroy(orc_env *e);
+
+/* reset(seed) when has_seed, else the build's deterministic unseeded rule. obs_out: D floats */
+void orc_env_reset(orc_env *e, int has_seed, uint64_t seed, float *obs_out);
+
+/* one step.  action: flat action (mono 0..21, press 0..10, sort 0..1).
+ * sort_mode: Env_2 only: <0 means the reference's rule-based fallback (sorting_rules).
+ * Returns 0, or nonzero on an invalid argument. */
+int orc_env_step(orc_env *e, int32_t action, int32_t sort_mode, uint32_t flags,
+                 float *obs_out, double *reward_out, int32_t *terminated_out);
+
+void orc_env_action_mask(const orc_env *e, uint8_t *mask_out);
+void orc_env_obs(const orc_env *e, float *obs_out);
+int  orc_env_obs_dim(const orc_env *e);
+int  orc_env_num_actions(const orc_env *e);
+
+/* snapshot: fixed layout shared with tests (see oracle/oracle.py SNAP_*) */
+#define ORC_SNAP_INTS 71
+#define ORC_SNAP_DBLS 8
+void orc_env_snapshot(const orc_env *e, int64_t *ints, double *dbls, uint64_t *rng_words /*[3*6]*/);
+
+/* run a masked-uniform random rollout of n_steps on one env with auto-reset (unseeded rule);
+ * used by bench.py's cpu_baseline leg.  Returns sum of rewards (to defeat dead-code elimination). */
+double orc_env_random_rollout(orc_env *e, int64_t n_steps, uint64_t policy_seed);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

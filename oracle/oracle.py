@@ -1,0 +1,195 @@
+"""ctypes front-end of the CPU ORACLE (oracle/mse_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg.  Nothing under marl-sortingenv_amd/ may import this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "libmse_oracle.so")
+
+ENV_SORT, ENV_PRESS, ENV_MONO = 1, 2, 3
+KIND_BY_NAME = {"sort": ENV_SORT, "press": ENV_PRESS, "mono": ENV_MONO}
+STEP_UNMASKED, STEP_CHECK_OVERFLOW = 1, 2
+
+SNAP_INTS, SNAP_DBLS = 71, 8
+# integer snapshot layout (orc_env_snapshot)
+SNAP = {
+    "input": slice(0, 4), "belt": slice(4, 8), "sorting": slice(8, 12),
+    "cont_true": slice(12, 16), "cont_false": slice(16, 20), "cont_e": slice(20, 21),
+    "press_timer": slice(21, 23), "press_mat": slice(23, 25), "press_n": slice(25, 27),
+    "press_q100": slice(27, 29), "mode": slice(29, 30), "last_press_started": slice(30, 31),
+    "last_press_amount": slice(31, 32), "current_step": slice(32, 33),
+    "gen_first": slice(33, 34), "gen_idx": slice(34, 35), "gen_counter": slice(35, 36),
+    "bale_count": slice(36, 41), "bale_sum": slice(41, 46), "bale_last_size": slice(46, 51),
+    "bale_last_q": slice(51, 56), "log_code": slice(56, 57), "log_mat": slice(57, 58),
+    "internal_press_action": slice(58, 59), "draws": slice(59, 60), "episode": slice(60, 61),
+}
+
+
+class Pcg64(C.Structure):
+    _fields_ = [("state_hi", C.c_uint64), ("state_lo", C.c_uint64), ("inc_hi", C.c_uint64),
+                ("inc_lo", C.c_uint64), ("has_uint32", C.c_int32), ("uinteger", C.c_uint32)]
+
+
+class Config(C.Structure):
+    _fields_ = [
+        ("input_occupancy_min", C.c_int32), ("input_occupancy_max", C.c_int32),
+        ("input_batch_size", C.c_int32), ("steps_per_pattern", C.c_int32),
+        ("baseline_accuracy", C.c_double * 4), ("boost", C.c_double), ("noise", C.c_double),
+        ("stage_capacity", C.c_int32),
+        ("press_time", C.c_int32 * 2), ("container_capacity", C.c_int32),
+        ("bale_standard_size", C.c_int32),
+        ("bale_remainder_threshold", C.c_double), ("quality_threshold", C.c_double * 4),
+        ("purity_threshold_theta", C.c_double), ("tanh_temperature", C.c_double),
+        ("overflow_penalty_catastrophic", C.c_double), ("overflow_penalty_severe", C.c_double),
+        ("overflow_penalty_mild", C.c_double),
+        ("bale_efficiency_factor", C.c_double), ("max_state_reward", C.c_double),
+        ("overflow_termination_penalty", C.c_double),
+        ("pattern_ratio", (C.c_double * 4) * 2),
+        ("env_kind", C.c_int32), ("max_steps", C.c_int32),
+    ]
+
+
+def build(force: bool = False) -> str:
+    """Compile the oracle with gcc (oracle/Makefile). Building the checker is not using it."""
+    src = os.path.join(_HERE, "mse_oracle.c")
+    hdr = os.path.join(_HERE, "mse_oracle.h")
+    stale = (not os.path.exists(_SO)) or any(
+        os.path.getmtime(p) > os.path.getmtime(_SO) for p in (src, hdr))
+    if force or stale:
+        subprocess.run(["make", "-C", _HERE, "-B" if force else "-s"], check=True,
+                       stdout=subprocess.DEVNULL)
+    return _SO
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_SO)
+        u64, i64, i32, u32, dbl = C.c_uint64, C.c_int64, C.c_int32, C.c_uint32, C.c_double
+        P = C.POINTER
+        L.orc_seed_sequence_u64x4.argtypes = [u64, P(u64)]
+        L.orc_pcg64_seed.argtypes = [P(Pcg64), u64]
+        L.orc_pcg64_next64.argtypes = [P(Pcg64)]
+        L.orc_pcg64_next64.restype = u64
+        L.orc_pcg64_next32.argtypes = [P(Pcg64)]
+        L.orc_pcg64_next32.restype = u32
+        L.orc_pcg64_random.argtypes = [P(Pcg64)]
+        L.orc_pcg64_random.restype = dbl
+        L.orc_pcg64_uniform.argtypes = [P(Pcg64), dbl, dbl]
+        L.orc_pcg64_uniform.restype = dbl
+        L.orc_pcg64_integers.argtypes = [P(Pcg64), i64, i64]
+        L.orc_pcg64_integers.restype = i64
+        L.orc_pcg64_choice_p.argtypes = [P(Pcg64), P(dbl), C.c_int]
+        L.orc_pcg64_choice_p.restype = C.c_int
+        L.orc_permutation12_first.argtypes = [u64]
+        L.orc_permutation12_first.restype = C.c_int
+        L.orc_round2.argtypes = [dbl]
+        L.orc_round2.restype = dbl
+        L.orc_rint_i64.argtypes = [dbl]
+        L.orc_rint_i64.restype = i64
+        L.orc_config_default.argtypes = [P(Config)]
+        L.orc_env_create.argtypes = [P(Config), C.c_int, u64]
+        L.orc_env_create.restype = C.c_void_p
+        L.orc_env_destroy.argtypes = [C.c_void_p]
+        L.orc_env_reset.argtypes = [C.c_void_p, C.c_int, u64, P(C.c_float)]
+        L.orc_env_step.argtypes = [C.c_void_p, i32, i32, u32, P(C.c_float), P(dbl), P(i32)]
+        L.orc_env_step.restype = C.c_int
+        L.orc_env_action_mask.argtypes = [C.c_void_p, P(C.c_uint8)]
+        L.orc_env_obs.argtypes = [C.c_void_p, P(C.c_float)]
+        L.orc_env_obs_dim.argtypes = [C.c_void_p]
+        L.orc_env_obs_dim.restype = C.c_int
+        L.orc_env_num_actions.argtypes = [C.c_void_p]
+        L.orc_env_num_actions.restype = C.c_int
+        L.orc_env_snapshot.argtypes = [C.c_void_p, P(i64), P(dbl), P(u64)]
+        L.orc_env_random_rollout.argtypes = [C.c_void_p, i64, u64]
+        L.orc_env_random_rollout.restype = dbl
+        _lib = L
+    return _lib
+
+
+def default_config(kind: int | str = ENV_MONO, max_steps: int = 50, noise: float = 0.05,
+                   balesize: int = 200) -> Config:
+    cfg = Config()
+    lib().orc_config_default(C.byref(cfg))
+    cfg.env_kind = KIND_BY_NAME[kind] if isinstance(kind, str) else int(kind)
+    cfg.max_steps = int(max_steps)
+    cfg.noise = float(noise)
+    cfg.bale_standard_size = int(balesize)
+    return cfg
+
+
+class OracleEnv:
+    """One scalar oracle env (mirrors the reference's single-env classes)."""
+
+    def __init__(self, kind="mono", max_steps=50, seed=None, noise_sorting=0.05, balesize=200,
+                 cfg: Config | None = None):
+        self.L = lib()
+        self.cfg = cfg if cfg is not None else default_config(kind, max_steps, noise_sorting, balesize)
+        self._h = self.L.orc_env_create(C.byref(self.cfg), 0 if seed is None else 1,
+                                        0 if seed is None else int(seed))
+        if not self._h:
+            raise MemoryError("orc_env_create failed")
+        self.obs_dim = self.L.orc_env_obs_dim(self._h)
+        self.num_actions = self.L.orc_env_num_actions(self._h)
+
+    def close(self):
+        if self._h:
+            self.L.orc_env_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def reset(self, seed=None):
+        obs = np.zeros(self.obs_dim, dtype=np.float32)
+        self.L.orc_env_reset(self._h, 0 if seed is None else 1, 0 if seed is None else int(seed),
+                             obs.ctypes.data_as(C.POINTER(C.c_float)))
+        return obs
+
+    def step(self, action, sort_mode=-1, use_action_masking=True, check_overflow=False):
+        obs = np.zeros(self.obs_dim, dtype=np.float32)
+        rew = C.c_double(0.0)
+        term = C.c_int32(0)
+        flags = (0 if use_action_masking else STEP_UNMASKED) | (STEP_CHECK_OVERFLOW if check_overflow else 0)
+        rc = self.L.orc_env_step(self._h, int(action), int(sort_mode), flags,
+                                 obs.ctypes.data_as(C.POINTER(C.c_float)), C.byref(rew), C.byref(term))
+        if rc != 0:
+            raise ValueError(f"orc_env_step failed rc={rc}")
+        return obs, rew.value, bool(term.value)
+
+    def action_masks(self):
+        m = np.zeros(self.num_actions, dtype=np.uint8)
+        self.L.orc_env_action_mask(self._h, m.ctypes.data_as(C.POINTER(C.c_uint8)))
+        return m
+
+    def obs(self):
+        o = np.zeros(self.obs_dim, dtype=np.float32)
+        self.L.orc_env_obs(self._h, o.ctypes.data_as(C.POINTER(C.c_float)))
+        return o
+
+    def snapshot(self):
+        ints = np.zeros(SNAP_INTS, dtype=np.int64)
+        dbls = np.zeros(SNAP_DBLS, dtype=np.float64)
+        rng = np.zeros(18, dtype=np.uint64)
+        self.L.orc_env_snapshot(self._h, ints.ctypes.data_as(C.POINTER(C.c_int64)),
+                                dbls.ctypes.data_as(C.POINTER(C.c_double)),
+                                rng.ctypes.data_as(C.POINTER(C.c_uint64)))
+        return ints, dbls, rng
+
+    def random_rollout(self, n_steps, policy_seed=2024):
+        return self.L.orc_env_random_rollout(self._h, int(n_steps), int(policy_seed))

@@ -1,0 +1,165 @@
+"""Import the reference (read-only checkout) in the BUILD CONTAINER to pin the oracle.
+
+TEST INFRASTRUCTURE ONLY, and only usable where /root/reference exists (it does not exist on
+the GPU box).  Used by oracle/gen_golden.py to generate tests/golden/*.npz and by
+tests/test_oracle_vs_reference.py (skipped when the checkout is absent).
+
+The reference imports three packages that are not installed here and that its step path never
+computes with: `gymnasium` (base class + space objects), `seaborn` and `cv2` (plotting).  They are
+replaced by inert placeholder modules below; no arithmetic of the path runs through them.
+The reference reads `config.yml` relative to the CWD (src/envs_train/env_super.py:25,28), hence
+the chdir.  Nothing of the reference is copied into this repository.
+"""
+from __future__ import annotations
+
+import os
+import sys
+import types
+
+import numpy as np
+
+REFERENCE_ROOT = os.environ.get("MSE_REFERENCE_ROOT", "/root/reference")
+MATERIALS = ["A", "B", "C", "D", "E"]
+
+
+def available() -> bool:
+    return os.path.isfile(os.path.join(REFERENCE_ROOT, "src", "envs_train", "env_super.py"))
+
+
+def _install_placeholders():
+    if "gymnasium" not in sys.modules:
+        gym = types.ModuleType("gymnasium")
+
+        class Env:  # minimal gymnasium.Env surface the reference touches
+            @property
+            def unwrapped(self):
+                return self
+
+            def close(self):
+                pass
+
+        class _Space:
+            def seed(self, seed=None):
+                return [seed]
+
+        class Box(_Space):
+            def __init__(self, low, high, shape=None, dtype=np.float32):
+                self.low = np.asarray(low, dtype=dtype)
+                self.high = np.asarray(high, dtype=dtype)
+                self.dtype = np.dtype(dtype)
+                self.shape = self.low.shape
+
+        class Discrete(_Space):
+            def __init__(self, n):
+                self.n = int(n)
+
+        spaces = types.ModuleType("gymnasium.spaces")
+        spaces.Box, spaces.Discrete = Box, Discrete
+        gym.Env, gym.spaces = Env, spaces
+        sys.modules["gymnasium"] = gym
+        sys.modules["gymnasium.spaces"] = spaces
+    for name in ("seaborn", "cv2"):
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+
+
+_classes = None
+
+
+def load():
+    """Returns {'sort': Env_1_Sorting, 'press': Env_2_Pressing, 'mono': Env_3_Monolith}."""
+    global _classes
+    if _classes is None:
+        if not available():
+            raise RuntimeError(f"reference checkout not found at {REFERENCE_ROOT}")
+        _install_placeholders()
+        import matplotlib
+
+        matplotlib.use("Agg")
+        if REFERENCE_ROOT not in sys.path:
+            sys.path.insert(0, REFERENCE_ROOT)
+        os.chdir(REFERENCE_ROOT)
+        from src.envs_train.env_1_sort import Env_1_Sorting
+        from src.envs_train.env_2_press import Env_2_Pressing
+        from src.envs_train.env_monolith import Env_3_Monolith
+
+        _classes = {"sort": Env_1_Sorting, "press": Env_2_Pressing, "mono": Env_3_Monolith}
+    return _classes
+
+
+class ScriptedSortAgent:
+    """Stands where the reference expects a trained sorting agent (Env_2.set_agents):
+    predict() returns the next scripted mode."""
+
+    def __init__(self):
+        self.next_mode = 0
+
+    def predict(self, obs, deterministic=True):
+        return int(self.next_mode), None
+
+
+def _rng_words(gen) -> list[int]:
+    st = gen.bit_generator.state
+    s, inc = int(st["state"]["state"]), int(st["state"]["inc"])
+    m = (1 << 64) - 1
+    return [s >> 64, s & m, inc >> 64, inc & m, int(st["has_uint32"]), int(st["uinteger"])]
+
+
+def snapshot(env):
+    """Same layout as orc_env_snapshot (oracle/oracle.py SNAP); fields the reference does not
+    have (draws, episode) are -1."""
+    from oracle.oracle import SNAP, SNAP_DBLS, SNAP_INTS  # layout only
+
+    I = np.zeros(SNAP_INTS, dtype=np.int64)
+    D = np.zeros(SNAP_DBLS, dtype=np.float64)
+    I[SNAP["input"]] = env.current_material_input
+    I[SNAP["belt"]] = env.current_material_belt
+    I[SNAP["sorting"]] = env.current_material_sorting
+    cm = env.container_materials
+    I[SNAP["cont_true"]] = [int(cm[m]) for m in "ABCD"]
+    I[SNAP["cont_false"]] = [int(cm[m + "_False"]) for m in "ABCD"]
+    I[SNAP["cont_e"]] = int(cm["E"])
+    ps = env.press_state
+    for p in (1, 2):
+        I[SNAP["press_timer"].start + p - 1] = int(ps[f"press_{p}"])
+        mat = ps[f"material_{p}"]
+        I[SNAP["press_mat"].start + p - 1] = MATERIALS.index(mat) if isinstance(mat, str) else -1
+        I[SNAP["press_n"].start + p - 1] = int(ps[f"n_{p}"])
+        I[SNAP["press_q100"].start + p - 1] = int(np.rint(float(ps[f"q_{p}"]) * 100.0))
+    I[SNAP["mode"]] = int(env.sensor_current_setting)
+    I[SNAP["last_press_started"]] = int(bool(env._last_press_started))
+    I[SNAP["last_press_amount"]] = int(env._last_press_amount)
+    I[SNAP["current_step"]] = int(env.current_step)
+    g = env.input_generator
+    I[SNAP["gen_first"]] = int(g.pattern_sequence[0])
+    I[SNAP["gen_idx"]] = int(g.current_pattern_idx)
+    I[SNAP["gen_counter"]] = int(g.step_counter)
+    for k, m in enumerate(MATERIALS):
+        bales = env.bale_count[m]
+        I[SNAP["bale_count"].start + k] = len(bales)
+        I[SNAP["bale_sum"].start + k] = sum(int(b[0]) for b in bales)
+        I[SNAP["bale_last_size"].start + k] = int(bales[-1][0]) if bales else 0
+        I[SNAP["bale_last_q"].start + k] = int(bales[-1][1]) if bales else 0
+    code, mat = -1, -1
+    if env.press_actions_per_timestep:
+        c, m = env.press_actions_per_timestep[-1]
+        code = int(c)
+        if isinstance(m, str):
+            mat = MATERIALS.index(m)
+        elif m is None:
+            mat = -1
+        else:
+            mat = int(m)
+    I[SNAP["log_code"]] = code
+    I[SNAP["log_mat"]] = mat
+    ipa = 0
+    if env.name == "sort" and code in (1, 2):
+        ipa = (code - 1) * 5 + mat + 1
+    I[SNAP["internal_press_action"]] = ipa
+    I[SNAP["draws"]] = -1
+    I[SNAP["episode"]] = -1
+    D[0:4] = env.accuracy_belt
+    D[4:8] = env.accuracy_sorter
+    R = np.array(_rng_words(env.rng) + _rng_words(env.rng_noise) + _rng_words(env.rng_pressing),
+                 dtype=np.uint64)
+    return I, D, R

@@ -1,0 +1,75 @@
+"""Replay a golden fixture (tests/golden/*.npz) on a driver and compare row by row.
+
+A driver exposes:  reset(seed)->obs   step(action, sort_mode, flags)->(obs, reward, terminated)
+                   action_masks()->u8[A]   snapshot()->(ints, dbls, rng) in oracle.SNAP layout
+Integer state, masks and PCG64 states must match bit for bit; obs are f32 and must match
+bit for bit; rewards within `reward_tol` (north_star: 1e-6; the oracle itself is compared at 1e-12,
+the only inexact operation being tanh).
+"""
+from __future__ import annotations
+
+import glob
+import json
+import os
+
+import numpy as np
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+# snapshot columns the reference does not define (filled with -1 by the generator)
+from oracle.oracle import SNAP  # noqa: E402
+
+_REF_UNDEFINED = [SNAP["draws"].start, SNAP["episode"].start]
+
+
+def fixtures(kind=None):
+    paths = sorted(glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+    if kind is not None:
+        paths = [p for p in paths if os.path.basename(p).startswith(kind + "_")]
+    return paths
+
+
+def load(path):
+    z = np.load(path, allow_pickle=False)
+    meta = json.loads(bytes(z["meta"]).decode())
+    return meta, z
+
+
+def compare_row(tag, z, t, obs, reward, term, mask, snap, reward_tol, skip_cols=()):
+    ints, dbls, rng = snap
+    exp_i = z["ints"][t].copy()
+    got_i = np.asarray(ints).copy()
+    for c in list(_REF_UNDEFINED) + list(skip_cols):
+        exp_i[c] = 0
+        got_i[c] = 0
+    if not np.array_equal(exp_i, got_i):
+        bad = np.flatnonzero(exp_i != got_i)
+        raise AssertionError(f"{tag} row {t}: integer state differs at cols {bad.tolist()}: "
+                             f"expected {exp_i[bad].tolist()} got {got_i[bad].tolist()}")
+    assert np.array_equal(z["mask"][t], np.asarray(mask, dtype=np.uint8)), f"{tag} row {t}: mask differs"
+    assert np.array_equal(z["rng"][t], np.asarray(rng, dtype=np.uint64)), \
+        f"{tag} row {t}: PCG64 state differs {z['rng'][t].tolist()} vs {np.asarray(rng).tolist()}"
+    assert np.array_equal(z["dbls"][t], np.asarray(dbls)), f"{tag} row {t}: accuracy doubles differ"
+    exp_o = z["obs"][t]
+    got_o = np.asarray(obs, dtype=np.float32)
+    if not np.array_equal(exp_o.view(np.uint32), got_o.view(np.uint32)):
+        bad = np.flatnonzero(exp_o.view(np.uint32) != got_o.view(np.uint32))
+        raise AssertionError(f"{tag} row {t}: obs differs at {bad.tolist()}: {exp_o[bad]} vs {got_o[bad]}")
+    assert int(z["terminated"][t]) == int(term), f"{tag} row {t}: terminated differs"
+    assert abs(float(z["reward"][t]) - float(reward)) <= reward_tol, \
+        f"{tag} row {t}: reward {reward!r} vs {float(z['reward'][t])!r}"
+
+
+def replay(path, make_driver, reward_tol=1e-6, skip_cols=()):
+    meta, z = load(path)
+    drv = make_driver(meta)
+    n = len(z["op"])
+    tag = meta["name"]
+    for t in range(n):
+        if z["op"][t] == 1:
+            obs = drv.reset(int(z["arg"][t]))
+            rew, term = 0.0, False
+        else:
+            obs, rew, term = drv.step(int(z["arg"][t]), int(z["sort_mode"][t]), int(z["flags"][t]))
+        compare_row(tag, z, t, obs, rew, term, drv.action_masks(), drv.snapshot(), reward_tol, skip_cols)
+    return n

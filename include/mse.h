@@ -1,0 +1,183 @@
+/*
+ * mse.h -- C ABI of libmse_hip.so: the MI355X-native batched step() engine for the three
+ * MARL-SortingEnv environments.
+ *
+ * The reference has no FFI: its boundary for this path is the Python Gymnasium protocol of
+ * Env_1_Sorting / Env_2_Pressing / Env_3_Monolith (one env instance, NumPy on the host).  Each
+ * entry point below names the reference interface it replaces (path:line in the reference
+ * checkout).  N independent env instances live in one handle, one env per GPU lane, state as
+ * struct-of-arrays planes in HBM that the library owns; every I/O buffer is CALLER-owned DEVICE
+ * memory (contiguous, row-major, 16-byte aligned), e.g. a PyTorch-ROCm tensor's data_ptr().
+ *
+ * Conventions
+ *   - every function returns 0 (MSE_OK) or a negative mse_status; nothing throws across the ABI;
+ *     mse_last_error() gives the message of the calling thread's last failure;
+ *   - all device work is enqueued on the caller's HIP stream (`stream` is a hipStream_t passed as
+ *     void*, NULL = the default stream); no hidden synchronisation, graph-capture safe
+ *     (mse_step / mse_rollout / mse_reset / mse_action_masks allocate nothing and never sync);
+ *   - a handle is not thread-safe; different handles are independent;
+ *   - there is NO CPU fallback: the library needs a gfx950 device and fails loudly without one.
+ */
+#ifndef MSE_H
+#define MSE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MSE_VERSION 100 /* 0.1.0 */
+
+typedef enum mse_status {
+    MSE_OK = 0,
+    MSE_ERR_INVALID_ARGUMENT = -1,
+    MSE_ERR_UNSUPPORTED_CONFIG = -2,
+    MSE_ERR_NO_DEVICE = -3,
+    MSE_ERR_HIP = -4,
+    MSE_ERR_NOT_RESET = -5,
+    MSE_ERR_ALIGNMENT = -6
+} mse_status;
+
+/* env_1_sort.py:26 "sort", env_2_press.py:26 "press", env_monolith.py:28 "mono" */
+typedef enum mse_env_kind { MSE_ENV_SORT = 1, MSE_ENV_PRESS = 2, MSE_ENV_MONO = 3 } mse_env_kind;
+
+/* per-call step flags = the reference's step() keyword arguments
+ * (env_monolith.py:109, env_2_press.py:88, env_1_sort.py:97) */
+#define MSE_STEP_UNMASKED       1u /* use_action_masking=False: validate + sanitise the press action */
+#define MSE_STEP_CHECK_OVERFLOW 2u /* check_overflow=True: overflow terminates with the -10 penalty  */
+
+/* POD copy of the reference's config.yml plus the env constructor arguments
+ * (env_super.py:25-137 reads the same keys; env_monolith.py:22-23 ctor). */
+typedef struct mse_config {
+    uint32_t struct_size;          /* = sizeof(mse_config); ABI check */
+    int32_t  env_kind;             /* mse_env_kind */
+    int32_t  max_steps;            /* ctor max_steps (<= 65535) */
+    int32_t  auto_reset;           /* 1: a terminated env is reset inside the same step (VecEnv semantics) */
+    int32_t  track_bales;          /* 1: keep the O(1) bale ledger summary (env_super.py:661-687) */
+    int32_t  literal_choice;       /* 1: always evaluate Generator.choice(4,p) in literal fp64 (test switch);
+                                      0: exact integer decision with literal fallback near ties */
+    /* simulation (config.yml:4-9) */
+    int32_t  input_batch_size;     /* <= 255, must leave no floor() remainder for both patterns */
+    int32_t  steps_per_pattern;    /* informational: reset() rebuilds the generator with its default 20
+                                      (env_super.py:375), so 20 is what every episode uses */
+    /* sorting_station (config.yml:12-18) */
+    double   baseline_accuracy[4];
+    double   boost;
+    double   noise;                /* ctor noise_sorting (env_super.py:71) */
+    int32_t  stage_capacity;
+    /* pressing_station (config.yml:21-32) */
+    int32_t  press_time[2];        /* <= 255 */
+    int32_t  container_capacity;
+    int32_t  bale_standard_size;   /* ctor balesize (env_super.py:87) */
+    double   bale_remainder_threshold;
+    double   quality_threshold[4];
+    double   quality_threshold_r2[4]; /* python round(threshold, 2): purity of an EMPTY container
+                                         (env_super.py:786-789) */
+    /* rewards (config.yml:35-59) */
+    double   purity_threshold_theta;
+    double   tanh_temperature;
+    double   overflow_penalty_catastrophic;
+    double   overflow_penalty_severe;
+    double   overflow_penalty_mild;
+    double   bale_efficiency_factor;
+    double   max_state_reward;
+    double   overflow_termination_penalty;
+    /* seasonal patterns 1 and 2, order A,B,C,D (utils/input_generator.py:17-20) */
+    double   pattern_ratio[2][4];
+} mse_config;
+
+typedef struct mse_env mse_env; /* opaque handle: N envs on one device */
+
+/* library */
+int         mse_version(void);
+const char *mse_last_error(void);
+const char *mse_status_string(int status);
+
+/* Fills *cfg with config.yml's values and the env classes' ctor defaults
+ * (max_steps=50, noise 0.05, balesize 200: env_monolith.py:22-23). */
+int mse_config_default(mse_config *cfg);
+
+/* Replaces Env_*.__init__ (env_monolith.py:22-36, env_super.py:25-137) for n_envs instances on
+ * HIP device `device_id`.  Allocates the state planes; the envs hold no valid episode until
+ * mse_reset() with seeds has run once (mse_step before that fails with MSE_ERR_NOT_RESET). */
+int mse_create(mse_env **out, const mse_config *cfg, int64_t n_envs, int device_id);
+/* Same, for one shard of a larger job: env i of this handle is global env index_offset + i.
+ * The global index only feeds the random-policy stream, so a sharded run samples the same
+ * actions as a single-handle run (env-index sharding). */
+int mse_create_indexed(mse_env **out, const mse_config *cfg, int64_t n_envs, int device_id, int64_t index_offset);
+int mse_destroy(mse_env *env);
+
+int64_t mse_num_envs(const mse_env *env);
+int     mse_obs_dim(const mse_env *env);      /* 13 / 16 / 29: observation_space (env_1_sort.py:71, env_2_press.py:62, env_monolith.py:72) */
+int     mse_num_actions(const mse_env *env);  /* 2 / 11 / 22: action_space      (env_1_sort.py:72, env_2_press.py:64, env_monolith.py:79) */
+
+/* Replaces Env_*.reset(seed=...) (env_super.py:365-420 and the variants' overrides
+ * env_1_sort.py:81-85, env_2_press.py:73-75, env_monolith.py:91-93).
+ *   seeds_dev  u64[N] or NULL.  Given: reset(seed=seeds[i]) - re-seeds the env's streams at
+ *              seed+3/+4/+99 and the generator at seed, all on the device (NumPy SeedSequence +
+ *              PCG64 restated).  NULL: reset(seed=None) - streams continue; the generator's
+ *              pattern order follows the build's deterministic rule (DESIGN.md "unseeded reset").
+ *   which_dev  u8[N] or NULL: only envs with which[i] != 0 are reset (NULL = all).
+ *   obs_out    f32[N, D] or NULL;  mask_out u8[N, A] or NULL  (rows of envs not reset are
+ *              rewritten with their current observation / mask). */
+int mse_reset(mse_env *env, const uint64_t *seeds_dev, const uint8_t *which_dev,
+              float *obs_out, uint8_t *mask_out, void *stream);
+
+/* Replaces Env_*.step(action, use_action_masking, check_overflow)
+ * (env_1_sort.py:97-154, env_2_press.py:88-165, env_monolith.py:109-284) for all N envs.
+ *   action_dev     i32[N]: sort: mode 0|1; press: 0..10; mono: 0..21 (mode*11 + press action).
+ *                  Out-of-range values are counted (mse_error_count) and treated as action 0.
+ *   sort_mode_dev  i32[N] or NULL, Env_2 only: the sorting agent's decision
+ *                  (env_2_press.py:101-104); NULL = the rule-based fallback sorting_rules()
+ *                  (env_super.py:469-482).
+ *   obs_out        f32[N, D]    next observation (after auto-reset: the reset observation)
+ *   reward_out     f32[N]       or NULL
+ *   reward64_out   f64[N]       or NULL (the reference returns a python float = f64)
+ *   done_out       u8[N]        terminated flag (truncated is always False in the reference)
+ *   mask_out       u8[N, A]     or NULL: action_masks() of the state the NEXT action sees
+ *   terminal_obs_out f32[N, D]  or NULL: with auto_reset, the last observation of a finished
+ *                  episode (rows of envs that did not finish are left untouched). */
+int mse_step(mse_env *env, const int32_t *action_dev, const int32_t *sort_mode_dev, uint32_t flags,
+             float *obs_out, float *reward_out, double *reward64_out, uint8_t *done_out,
+             uint8_t *mask_out, float *terminal_obs_out, void *stream);
+
+/* Replaces Env_*.action_masks() (env_monolith.py:81-85 -> env_super.py:887-898,
+ * env_2_press.py:66-67 -> env_super.py:869-885, env_1_sort.py:74-76). mask_out u8[N, A]. */
+int mse_action_masks(mse_env *env, uint8_t *mask_out, void *stream);
+
+/* K fused steps with the on-device masked-uniform random policy (the reference's
+ * mode='random' with masking, env_monolith.py:152-158, with a counter-based policy stream
+ * instead of the global np.random).  State stays in registers across the K steps.
+ * Outputs are step-major: actions_out i32[K,N], obs_out f32[K,N,D], reward_out f32[K,N],
+ * done_out u8[K,N], mask_out u8[K,N,A]; any of them may be NULL.  Needs auto_reset=1.
+ *   sort_mode_dev i32[N] or NULL: Env_2's frozen per-env sorting decision (NULL = rule). */
+int mse_rollout(mse_env *env, int32_t k_steps, uint64_t policy_seed, const int32_t *sort_mode_dev,
+                uint32_t flags, int32_t *actions_out, float *obs_out, float *reward_out,
+                uint8_t *done_out, uint8_t *mask_out, void *stream);
+
+/* Samples one masked-uniform action per env from the CURRENT state (same policy stream as
+ * mse_rollout); action_out i32[N]. */
+int mse_sample_actions(mse_env *env, uint64_t policy_seed, int32_t *action_out, void *stream);
+
+/* State export / import in a fixed record layout (tests, checkpoint/resume, dashboard trace):
+ *   ints  i64[N, MSE_SNAP_INTS]  (column map: MSE_SNAP_* below)
+ *   dbls  f64[N, 4]              accuracy_belt
+ *   rng   u64[N, 18]             {state_hi,state_lo,inc_hi,inc_lo,has_uint32,uinteger} x
+ *                                {rng (seed+99), rng_noise (seed+4), rng_pressing (seed+3)}
+ * Replaces reading/writing the attributes of Env_Super (env_super.py:52-137). */
+#define MSE_SNAP_INTS 71
+int mse_get_state(mse_env *env, int64_t *ints_out, double *dbls_out, uint64_t *rng_out, void *stream);
+int mse_set_state(mse_env *env, const int64_t *ints_in, const double *dbls_in, const uint64_t *rng_in, void *stream);
+
+/* Number of out-of-range actions seen so far (synchronises the device). */
+int mse_error_count(mse_env *env, uint64_t *count_out);
+
+/* Algorithmic HBM bytes per env-step used for the roofline figure. */
+int mse_algorithmic_bytes_per_step(const mse_env *env);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MSE_H */

@@ -1,0 +1,46 @@
+"""Builds libmse_hip.so (the C-ABI HIP library) in-tree with hipcc for gfx950."""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+REPO_ROOT = os.path.dirname(PKG_DIR)
+SOURCES = [os.path.join(PKG_DIR, "csrc", "mse_lib.hip")]
+HEADERS = [os.path.join(PKG_DIR, "csrc", "mse_device.h"), os.path.join(REPO_ROOT, "include", "mse.h")]
+LIB_PATH = os.path.join(PKG_DIR, "libmse_hip.so")
+
+HIPCC_FLAGS = [
+    "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared",
+    # numpy evaluates the restated fp64 expressions with separately rounded operations
+    "-ffp-contract=off", "-fno-fast-math",
+]
+
+
+def hipcc_path() -> str:
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: libmse_hip.so cannot be built")
+
+
+def is_stale() -> bool:
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    return any(os.path.getmtime(p) > t for p in SOURCES + HEADERS)
+
+
+def build_library(force: bool = False, verbose: bool = False) -> str:
+    if not force and not is_stale():
+        return LIB_PATH
+    cmd = [hipcc_path(), *HIPCC_FLAGS, "-I", os.path.join(REPO_ROOT, "include"), *SOURCES, "-o", LIB_PATH]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build_library(force=True, verbose=True))

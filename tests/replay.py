@@ -35,7 +35,7 @@ def load(path):
     return meta, z
 
 
-def compare_row(tag, z, t, obs, reward, term, mask, snap, reward_tol, skip_cols=()):
+def compare_row(tag, z, t, obs, reward, term, mask, snap, reward_tol, skip_cols=(), skip_rng_words=()):
     ints, dbls, rng = snap
     exp_i = z["ints"][t].copy()
     got_i = np.asarray(ints).copy()
@@ -47,8 +47,13 @@ def compare_row(tag, z, t, obs, reward, term, mask, snap, reward_tol, skip_cols=
         raise AssertionError(f"{tag} row {t}: integer state differs at cols {bad.tolist()}: "
                              f"expected {exp_i[bad].tolist()} got {got_i[bad].tolist()}")
     assert np.array_equal(z["mask"][t], np.asarray(mask, dtype=np.uint8)), f"{tag} row {t}: mask differs"
-    assert np.array_equal(z["rng"][t], np.asarray(rng, dtype=np.uint64)), \
-        f"{tag} row {t}: PCG64 state differs {z['rng'][t].tolist()} vs {np.asarray(rng).tolist()}"
+    exp_r = z["rng"][t].copy()
+    got_r = np.asarray(rng, dtype=np.uint64).copy()
+    for c in skip_rng_words:
+        exp_r[c] = 0
+        got_r[c] = 0
+    assert np.array_equal(exp_r, got_r), \
+        f"{tag} row {t}: PCG64 state differs {exp_r.tolist()} vs {got_r.tolist()}"
     assert np.array_equal(z["dbls"][t], np.asarray(dbls)), f"{tag} row {t}: accuracy doubles differ"
     exp_o = z["obs"][t]
     got_o = np.asarray(obs, dtype=np.float32)
@@ -60,16 +65,20 @@ def compare_row(tag, z, t, obs, reward, term, mask, snap, reward_tol, skip_cols=
         f"{tag} row {t}: reward {reward!r} vs {float(z['reward'][t])!r}"
 
 
-def replay(path, make_driver, reward_tol=1e-6, skip_cols=()):
+def replay(path, make_driver, reward_tol=1e-6, skip_cols=(), skip_rng_words=None):
     meta, z = load(path)
     drv = make_driver(meta)
     n = len(z["op"])
     tag = meta["name"]
+    if callable(skip_rng_words):
+        skip_rng_words = skip_rng_words(meta)
+    skip_rng_words = tuple(skip_rng_words or ())
     for t in range(n):
         if z["op"][t] == 1:
             obs = drv.reset(int(z["arg"][t]))
             rew, term = 0.0, False
         else:
             obs, rew, term = drv.step(int(z["arg"][t]), int(z["sort_mode"][t]), int(z["flags"][t]))
-        compare_row(tag, z, t, obs, rew, term, drv.action_masks(), drv.snapshot(), reward_tol, skip_cols)
+        compare_row(tag, z, t, obs, rew, term, drv.action_masks(), drv.snapshot(), reward_tol, skip_cols,
+                    skip_rng_words)
     return n

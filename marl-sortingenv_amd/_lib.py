@@ -59,6 +59,10 @@ def load_library() -> C.CDLL:
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python __graft_entry__.py` or "
             "`python marl-sortingenv_amd/build.py`. There is no CPU fallback for the step path.")
+    # PyTorch-ROCm bundles its own HIP runtime (same SONAME as ROCm's). Import it first so that
+    # libmse_hip.so binds to the runtime torch uses: streams and device pointers are shared objects.
+    import torch  # noqa: F401
+
     L = C.CDLL(LIB_PATH)
     vp, i32, i64, u32, u64 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32, C.c_uint64
     L.mse_version.restype = C.c_int

@@ -752,7 +752,6 @@ __device__ __forceinline__ void reset_episode_state(Env &e, const Params &P)
     e.gen_idx = 0;
     e.gen_cnt = 0;
     e.step = 0;
-    e.episode += 1u;
 }
 
 __device__ __forceinline__ void clear_bales(uint4 *__restrict__ planes, long long n_pad, long long i)

@@ -69,6 +69,7 @@ __device__ __forceinline__ void auto_reset_env(Env &e, const Params &P, uint4 *_
                                                double purity[4])
 {
     e.gen2 = unseeded_gen2(e);
+    e.episode += 1u;
     reset_episode_state(e, P);
     if (P.track_bales) clear_bales(planes, P.n_pad, i);
 #pragma unroll
@@ -207,9 +208,11 @@ __global__ __launch_bounds__(kBlock) void k_reset(Params P, uint4 *__restrict__ 
             e.press_uint = 0;
             e.noise = pcg_seed(seed + 4);
             e.rng = pcg_seed(seed + 99);
+            e.episode = 1u; // episodes are counted from the last seeded reset
             reseeded = true;
         } else {
             e.gen2 = unseeded_gen2(e);
+            e.episode += 1u;
         }
         reset_episode_state(e, P);
         clear_bales(planes, P.n_pad, i);

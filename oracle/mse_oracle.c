@@ -252,7 +252,8 @@ void orc_config_default(orc_config *c)
 /* The build's own rule for reset(seed=None): the reference seeds a fresh generator from OS
  * entropy there (env_super.py:375), which is not reproducible and therefore excluded from
  * parity.  Rule (shared with the HIP path): first pattern = 1 + (splitmix64_finalizer(
- * inc_lo(rng) ^ episode * 0x9E3779B97F4A7C15) & 1), episode = number of resets so far. */
+ * inc_lo(rng) ^ episode * 0x9E3779B97F4A7C15) & 1), episode = number of resets since (and
+ * including) the last seeded one. */
 static uint64_t mix64(uint64_t z)
 {
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
@@ -460,12 +461,13 @@ void orc_env_reset(orc_env *e, int has_seed, uint64_t seed, float *obs_out)
     if (has_seed) {
         e->gen_first = orc_permutation12_first(seed);
         env_set_seed(e, seed); /* env_super.py:377-378 */
+        e->episode = 1;        /* episodes are counted from the last seeded reset */
     } else {
         e->gen_first = unseeded_first_pattern(e);
+        e->episode++;
     }
     e->gen_idx = 0;
     e->gen_counter = 0;
-    e->episode++;
 
     for (int p = 0; p < 2; ++p) {
         e->press_timer[p] = 0;

@@ -142,7 +142,9 @@ def test_full_size_properties(kind, n):
         assert float(buf["obs"].min()) >= -1.0 and float(buf["obs"].max()) <= 1.0
     ints, _, _ = env.get_state()
     S = SNAP
-    in_system = (ints[:, S["input"]].sum(1) + ints[:, S["belt"]].sum(1) + ints[:, S["sorting"]].sum(1)
+    # the sorting stage is not counted: at the end of a step it has already been sorted into the
+    # containers but still shows its last content (the reference checks at the end of the flow update)
+    in_system = (ints[:, S["input"]].sum(1) + ints[:, S["belt"]].sum(1)
                  + ints[:, S["cont_true"]].sum(1) + ints[:, S["cont_false"]].sum(1) + ints[:, S["cont_e"]].sum(1)
                  + ints[:, S["press_n"]].sum(1) + ints[:, S["bale_sum"]].sum(1))
     step_col = ints[:, S["current_step"]].squeeze(1)

@@ -6,6 +6,14 @@
 //
 // The arithmetic follows the reference (citations = path:line in the reference checkout) and
 // numpy 2.2.6's Generator/PCG64/SeedSequence.  All fp64 work is compiled with -ffp-contract=off.
+//
+// Instruction-count discipline (the kernel is VALU-issue bound at one wave per SIMD, see
+// DESIGN.md "Kernel"): every quotient of small integers that the reference evaluates per step
+// (levels/700, timers/12, belt shares, purity differences ...) is a lookup in tables that the host
+// fills with the reference's literal fp64 expression (mse_lib.hip build_tables), staged in LDS;
+// the stage vectors are carried as seasonal-pattern ids; the sort_material draw decides
+// Generator.choice with integer compares on the PCG64 output and falls back to the literal fp64
+// cdf only within a hair of a tie.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -41,6 +49,12 @@ constexpr uint32_t FL_LAST_PRESS_STARTED = 1u;
 constexpr uint32_t FL_GEN_FIRST_IS_2 = 2u;
 constexpr uint32_t FL_PRESS_HAS_U32 = 4u;
 
+constexpr int kPdiffStride = 102; // purity hundredths 0..100, [101] = empty container
+// per-stage-id record in the LDS table image (12 words, 16-byte aligned):
+//   [0] packed counts  [1] belt_occupancy f32  [2] sorting_rules() mode  [3] pad
+//   [4..7] belt proportions f32   [8..11] sorting[m]/stage_capacity f32
+constexpr int kPatStride = 12;
+
 struct Params {
     long long n;            // envs in this handle
     long long n_pad;        // plane stride (multiple of kBlock)
@@ -48,28 +62,51 @@ struct Params {
     int env_kind, max_steps, auto_reset, track_bales;
     int balesize, capacity, stage_capacity, batch;
     int press_time[2];
-    int pat[2][4];          // floor(ratio * batch) per pattern, order A..D
+    // stage vectors are one of three words: id 0 = empty (after reset), 1 / 2 = seasonal pattern
+    uint32_t pat_word[3];   // packed u8x4 counts A..D (load/store conversion only; the step reads the LDS copy)
+    int thr_sev, thr_mild;  // levels above these have fill_ratio > 0.95 / > 0.90 (literal fp64 scan on the host)
+    int k_thr[4];           // hundredths of python round(quality_threshold, 2): purity of an empty container
     double base_acc[4], boost, noise;
-    double thr[4], thr_r2[4];
-    double theta, temperature;
-    double pen_cat, pen_sev, pen_mild, bef, max_state_reward, overflow_pen, rem_thr;
+    double pen_cat, pen_sev, pen_mild, max_state_reward, overflow_pen, rem_thr;
+    // offsets (in 4-byte words) into the table image; see build_tables
+    int off_lvl, off_pdiff, off_timer0, off_timer1, off_tanh, off_eff, off_pat, off_acc, off_bonus, off_ptime, table_words;
 };
 
 // ------------------------------------------------------------------------------------------
 // numpy PCG64 (pcg64.h): 128-bit LCG, XSL-RR output of the NEW state
 // ------------------------------------------------------------------------------------------
-constexpr uint64_t kMulLo = 0x4385DF649FCCF645ull;
-constexpr uint64_t kMulHi = 0x2360ED051FC65DA4ull;
-
 struct Pcg {
     uint64_t s_lo, s_hi, i_lo, i_hi;
 };
 
+// d = a * b + c on the 32x32+64 multiplier (v_mad_u64_u32; carry-out unused: callers never overflow
+// or work mod 2^64)
+__device__ __forceinline__ uint64_t mad64(uint32_t a, uint32_t b, uint64_t c)
+{
+    uint64_t d, carry;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(d), "=s"(carry) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+
+// state = state * 0x2360ED051FC65DA44385DF649FCCF645 + inc  (mod 2^128), on 32-bit limbs:
+// 6 v_mad_u64_u32 + 4 v_mul_lo_u32 (the minimum for a 128-bit constant multiplier) + carries
 __device__ __forceinline__ void pcg_advance(Pcg &g)
 {
-    uint64_t lo = g.s_lo * kMulLo;
-    uint64_t hi = __umul64hi(g.s_lo, kMulLo) + g.s_lo * kMulHi + g.s_hi * kMulLo;
-    uint64_t rlo = lo + g.i_lo;
+    const uint32_t m0 = 0x9FCCF645u, m1 = 0x4385DF64u, m2 = 0x1FC65DA4u, m3 = 0x2360ED05u;
+    const uint32_t s0 = (uint32_t)g.s_lo, s1 = (uint32_t)(g.s_lo >> 32);
+    const uint32_t s2 = (uint32_t)g.s_hi, s3 = (uint32_t)(g.s_hi >> 32);
+    const uint64_t p0 = mad64(s0, m0, 0ull);
+    const uint64_t t1 = mad64(s0, m1, p0 >> 32);          // <= (2^32-1)^2 + 2^32-1 : no overflow
+    const uint64_t t2 = mad64(s1, m0, (uint64_t)(uint32_t)t1);
+    const uint64_t lo = (uint64_t)(uint32_t)p0 | (t2 << 32);
+    // limbs 2..3, everything mod 2^64
+    uint64_t hi = (t1 >> 32) + (t2 >> 32);
+    hi = mad64(s0, m2, hi);
+    hi = mad64(s1, m1, hi);
+    hi = mad64(s2, m0, hi);
+    const uint32_t top = s0 * m3 + s1 * m2 + s2 * m1 + s3 * m0;
+    hi = (uint64_t)(uint32_t)hi | ((uint64_t)((uint32_t)(hi >> 32) + top) << 32);
+    const uint64_t rlo = lo + g.i_lo;
     hi += g.i_hi + (rlo < lo ? 1ull : 0ull);
     g.s_lo = rlo;
     g.s_hi = hi;
@@ -80,6 +117,17 @@ __device__ __forceinline__ uint64_t pcg_output(const Pcg &g)
     uint64_t x = g.s_hi ^ g.s_lo;
     unsigned rot = (unsigned)(g.s_hi >> 58);
     return (x >> rot) | (x << ((64u - rot) & 63u));
+}
+
+// upper 32 bits of the XSL-RR output only (all the integer draw decision needs)
+__device__ __forceinline__ uint32_t pcg_output_hi32(const Pcg &g)
+{
+    uint32_t x0 = (uint32_t)g.s_lo ^ (uint32_t)g.s_hi;
+    uint32_t x1 = (uint32_t)(g.s_lo >> 32) ^ (uint32_t)(g.s_hi >> 32);
+    uint32_t rot = (uint32_t)(g.s_hi >> 58);
+    bool swap = (rot & 32u) != 0u;
+    uint32_t a = swap ? x1 : x0, b = swap ? x0 : x1;
+    return __builtin_amdgcn_alignbit(a, b, rot & 31u); // ({a,b} >> rot)[31:0]
 }
 
 __device__ __forceinline__ uint64_t pcg_next64(Pcg &g)
@@ -182,9 +230,6 @@ __device__ __forceinline__ int select_kth_bit(uint32_t bits, int k)
     return __ffs((int)bits) - 1;
 }
 
-// round(np.float64, 2): multiply, rint (half-even), divide
-__device__ __forceinline__ double round2(double x) { return rint(x * 100.0) / 100.0; }
-
 // ------------------------------------------------------------------------------------------
 // per-env register image
 // ------------------------------------------------------------------------------------------
@@ -197,27 +242,25 @@ struct Env {
     double acc[4];      // accuracy_belt
     int ct[4], cf[4], ce;
     int pn[2], lpa;
-    int in[4], belt[4], sort[4];
+    int st_in, st_belt, st_sort; // stage ids: 0 empty, 1 / 2 seasonal pattern
     int timer[2], pmat[2], q100[2];
     int mode, lps, gen2, gen_idx, gen_cnt, step;
     uint32_t episode;
 };
 
-__device__ __forceinline__ void unpack4(uint32_t w, int v[4])
+__device__ __forceinline__ int stage_id(uint32_t word, const Params &P)
 {
-    v[0] = (int)(w & 0xFFu);
-    v[1] = (int)((w >> 8) & 0xFFu);
-    v[2] = (int)((w >> 16) & 0xFFu);
-    v[3] = (int)(w >> 24);
+    return word == 0u ? 0 : (word == P.pat_word[1] ? 1 : 2);
 }
-__device__ __forceinline__ uint32_t pack4(const int v[4])
+__device__ __forceinline__ uint32_t stage_word(int id, const Params &P)
 {
-    return (uint32_t)v[0] | ((uint32_t)v[1] << 8) | ((uint32_t)v[2] << 16) | ((uint32_t)v[3] << 24);
+    return id == 0 ? P.pat_word[0] : (id == 1 ? P.pat_word[1] : P.pat_word[2]);
 }
 
 template <int KIND, bool NOISE>
-__device__ __forceinline__ void load_env(Env &e, const uint4 *__restrict__ planes, long long n_pad, long long i)
+__device__ __forceinline__ void load_env(Env &e, const uint4 *__restrict__ planes, const Params &P, long long i)
 {
+    const long long n_pad = P.n_pad;
     uint4 a = planes[PL_RNG_STATE * n_pad + i];
     uint4 b = planes[PL_RNG_INC * n_pad + i];
     uint4 c0 = planes[PL_ACC01 * n_pad + i];
@@ -238,9 +281,9 @@ __device__ __forceinline__ void load_env(Env &e, const uint4 *__restrict__ plane
     e.ct[0] = (int)t.x; e.ct[1] = (int)t.y; e.ct[2] = (int)t.z; e.ct[3] = (int)t.w;
     e.cf[0] = (int)f.x; e.cf[1] = (int)f.y; e.cf[2] = (int)f.z; e.cf[3] = (int)f.w;
     e.ce = (int)m0.x; e.pn[0] = (int)m0.y; e.pn[1] = (int)m0.z; e.lpa = (int)m0.w;
-    unpack4(m1.x, e.in);
-    unpack4(m1.y, e.belt);
-    unpack4(m1.z, e.sort);
+    e.st_in = stage_id(m1.x, P);
+    e.st_belt = stage_id(m1.y, P);
+    e.st_sort = stage_id(m1.z, P);
     e.timer[0] = (int)(m1.w & 0xFFu);
     e.timer[1] = (int)((m1.w >> 8) & 0xFFu);
     e.pmat[0] = (int)((m1.w >> 16) & 0xFFu);
@@ -288,9 +331,10 @@ __device__ __forceinline__ uint4 pack_f64x2(double a, double b)
 
 // write_inc: the increments only change on a seeded reset
 template <int KIND, bool NOISE>
-__device__ __forceinline__ void store_env(const Env &e, uint4 *__restrict__ planes, long long n_pad, long long i,
+__device__ __forceinline__ void store_env(const Env &e, uint4 *__restrict__ planes, const Params &P, long long i,
                                           bool write_inc)
 {
+    const long long n_pad = P.n_pad;
     planes[PL_RNG_STATE * n_pad + i] = pack_u64x2(e.rng.s_lo, e.rng.s_hi);
     if (write_inc) planes[PL_RNG_INC * n_pad + i] = pack_u64x2(e.rng.i_lo, e.rng.i_hi);
     planes[PL_ACC01 * n_pad + i] = pack_f64x2(e.acc[0], e.acc[1]);
@@ -300,7 +344,7 @@ __device__ __forceinline__ void store_env(const Env &e, uint4 *__restrict__ plan
     planes[PL_MISC0 * n_pad + i] = make_uint4((uint32_t)e.ce, (uint32_t)e.pn[0], (uint32_t)e.pn[1], (uint32_t)e.lpa);
     uint32_t tw = (uint32_t)e.timer[0] | ((uint32_t)e.timer[1] << 8) | ((uint32_t)(e.pmat[0] & 0xFF) << 16) |
                   ((uint32_t)(e.pmat[1] & 0xFF) << 24);
-    planes[PL_MISC1 * n_pad + i] = make_uint4(pack4(e.in), pack4(e.belt), pack4(e.sort), tw);
+    planes[PL_MISC1 * n_pad + i] = make_uint4(stage_word(e.st_in, P), stage_word(e.st_belt, P), stage_word(e.st_sort, P), tw);
     uint32_t fl = (e.lps ? FL_LAST_PRESS_STARTED : 0u) | (e.gen2 ? FL_GEN_FIRST_IS_2 : 0u) |
                   (e.press_has ? FL_PRESS_HAS_U32 : 0u);
     uint32_t x = (uint32_t)e.q100[0] | ((uint32_t)e.q100[1] << 8) | ((uint32_t)e.mode << 16) | (fl << 24);
@@ -342,80 +386,80 @@ __device__ __forceinline__ uint32_t action_mask_bits(const Env &e, const Params 
     return KIND == 2 ? m : (m | (m << 11));
 }
 
+// press action a in 1..10 -> (press index 0|1, material 0..4)  (env_super.py:804-809)
+__device__ __forceinline__ void decode_press_action(int a, int &press, int &mat)
+{
+    press = a > 5 ? 1 : 0;
+    mat = a - 1 - 5 * press;
+}
+
 // env_super.py:811-836 validate_press_action
 __device__ __forceinline__ bool press_action_valid(const Env &e, const Params &P, int a)
 {
     if (a == 0) return true;
-    int press = a <= 5 ? 0 : 1;
-    int mat = (a - 1) % 5;
-    if (e.timer[press] > 0) return false;
-    int lvl = 0;
+    int press, mat;
+    decode_press_action(a, press, mat);
+    int tm = press ? e.timer[1] : e.timer[0];
+    if (tm > 0) return false;
+    int lvl = e.ce;
 #pragma unroll
-    for (int m = 0; m < 5; ++m) lvl = (mat == m) ? level_of(e, m) : lvl;
+    for (int m = 0; m < 4; ++m) lvl = (mat == m) ? e.ct[m] + e.cf[m] : lvl;
     return lvl >= P.balesize;
 }
 
-// SeasonalInputGenerator.generate_input reduced to material counts (utils/input_generator.py:37-64)
-// followed by env_super.py:433-461 update_environment
-__device__ __forceinline__ void update_environment(Env &e, const Params &P)
+// SeasonalInputGenerator.generate_input reduced to the pattern id (utils/input_generator.py:37-64;
+// with a remainder-free batch the material counts are a function of the pattern alone) followed by
+// env_super.py:433-461 update_environment
+__device__ __forceinline__ void update_environment(Env &e)
 {
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        e.sort[m] = e.belt[m];
-        e.belt[m] = e.in[m];
-    }
+    e.st_sort = e.st_belt;
+    e.st_belt = e.st_in;
     if (e.gen_cnt >= kGeneratorPeriod) {
         e.gen_idx ^= 1;
         e.gen_cnt = 0;
     }
-    int pat2 = e.gen_idx ^ e.gen2; // 1 -> pattern key 2
-#pragma unroll
-    for (int m = 0; m < 4; ++m) e.in[m] = pat2 ? P.pat[1][m] : P.pat[0][m];
+    e.st_in = 1 + (e.gen_idx ^ e.gen2);
     e.gen_cnt += 1;
 }
 
 // env_super.py:484-509 set_multisensor_mode + update_accuracy; acc_sorter gets the OLD accuracy_belt
 template <bool NOISE>
-__device__ __forceinline__ void update_accuracy(Env &e, const Params &P, int mode, double acc_sorter[4])
+__device__ __forceinline__ void update_accuracy(Env &e, const Params &P, const double *acc_table, int mode,
+                                                double acc_sorter[4])
 {
 #pragma unroll
     for (int m = 0; m < 4; ++m) acc_sorter[m] = e.acc[m];
     e.mode = mode;
+    if (NOISE) {
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        double a = P.base_acc[m];
-        bool boosted = (mode == 0 && (m == 0 || m == 2)) || (mode == 1 && (m == 1 || m == 3));
-        if (boosted) a = a + P.boost;
-        double nz;
-        if (NOISE) {
+        for (int m = 0; m < 4; ++m) {
+            bool boosted = (m == 0 || m == 2) ? (mode == 0) : (mode == 1);
+            double a = P.base_acc[m];
+            if (boosted) a = a + P.boost;
             // Generator.uniform(-n, n): low + (high-low)*random(), separately rounded
             double range = P.noise - (-P.noise);
             double u = u64_to_unit_double(pcg_next64(e.noise));
             double scaled = range * u;
-            nz = (-P.noise) + scaled;
-        } else {
-            nz = 0.0; // uniform(-0, 0) = -0 + 0*u = 0 (the stream still advances in the reference, unobservably)
+            double v = a + ((-P.noise) + scaled);
+            e.acc[m] = v < 0.0 ? 0.0 : (v > 1.0 ? 1.0 : v);
         }
-        double v = a + nz;
-        e.acc[m] = v < 0.0 ? 0.0 : (v > 1.0 ? 1.0 : v);
+    } else {
+        // noise == 0: clip(acc + 0) by mode from the table (modes other than 0/1 boost nothing: row 2);
+        // the reference still advances rng_noise here, unobservably
+        const double *row = acc_table + 4 * (mode == 0 ? 0 : (mode == 1 ? 1 : 2));
+#pragma unroll
+        for (int m = 0; m < 4; ++m) e.acc[m] = row[m];
     }
 }
 
-__device__ __forceinline__ int sel4(const int v[4], int k)
-{
-    return k == 0 ? v[0] : (k == 1 ? v[1] : (k == 2 ? v[2] : v[3]));
-}
-__device__ __forceinline__ double sel4d(const double v[4], int k)
-{
-    return k == 0 ? v[0] : (k == 1 ? v[1] : (k == 2 ? v[2] : v[3]));
-}
-
 // Generator.choice(4, p=leftover/total), literal fp64 evaluation (numpy _generator.pyx):
-// cdf = cumsum(p); cdf /= cdf[-1]; idx = searchsorted(cdf, u, 'right')
-__device__ __forceinline__ int choice4_literal(const int l[4], int total, uint64_t r64)
+// cdf = cumsum(p); cdf /= cdf[-1]; idx = searchsorted(cdf, u, 'right').   C = byte prefix sums of leftover.
+__device__ __forceinline__ int choice4_literal(uint32_t C, uint64_t r64)
 {
-    double T = (double)total;
-    double p0 = (double)l[0] / T, p1 = (double)l[1] / T, p2 = (double)l[2] / T, p3 = (double)l[3] / T;
+    const uint32_t L = C - (C << 8); // bytes l_0..l_3 (prefix sums are monotone: no borrows)
+    int l0 = (int)(L & 0xFFu), l1 = (int)((L >> 8) & 0xFFu), l2 = (int)((L >> 16) & 0xFFu), l3 = (int)(L >> 24);
+    double T = (double)(C >> 24);
+    double p0 = (double)l0 / T, p1 = (double)l1 / T, p2 = (double)l2 / T, p3 = (double)l3 / T;
     double c0 = p0;
     double c1 = c0 + p1;
     double c2 = c1 + p2;
@@ -425,64 +469,84 @@ __device__ __forceinline__ int choice4_literal(const int l[4], int total, uint64
     return (n0 <= u ? 1 : 0) + (n1 <= u ? 1 : 0) + (n2 <= u ? 1 : 0) + (n3 <= u ? 1 : 0);
 }
 
-// Exact decision of the same draw without fp64: with U = r64 >> 11 (u = U / 2^53) the literal cdf
-// compare `cdf_k <= u` equals `c_k <= floor(u*T)` (c_k = integer prefix sums of leftover) unless
-// u*T lies within ~2^-41 of an integer, which is excluded with a wide margin by looking at the
-// 32 fractional bits f of (r64 >> 32) * T; only then the literal path runs.  DESIGN.md "choice".
-__device__ __forceinline__ int choice4(const int l[4], int total, uint64_t r64, bool literal_only)
-{
-    uint64_t prod = (uint64_t)(uint32_t)(r64 >> 32) * (uint64_t)(uint32_t)total;
-    uint32_t f = (uint32_t)prod;
-    int v = (int)(prod >> 32);
-    bool safe = (f >= 16u) && (f < 0xFFFFFE00u);
-    if (literal_only || !safe) return choice4_literal(l, total, r64);
-    int c0 = l[0], c1 = c0 + l[1], c2 = c1 + l[2];
-    return (c0 <= v ? 1 : 0) + (c1 <= v ? 1 : 0) + (c2 <= v ? 1 : 0);
-}
-
-// env_super.py:511-609 sort_material.  The four stations are walked as one flattened loop so a
-// wave runs max-over-lanes(total draws) iterations instead of the sum of per-station maxima.
+// env_super.py:511-609 sort_material.
+//
+// leftover[4] is carried as the four byte-wise PREFIX SUMS C = {c_0, c_1, c_2, c_3 = T} in one register
+// (every count <= batch <= 127 on this path, so bytes never carry or borrow).
+//
+// One draw (env_super.py:553-571) = one PCG64 output r.  With U = r >> 11 (u = U/2^53) numpy's
+// `cdf_k <= u` equals `c_k <= floor(u*T)` unless u*T is within ~2^-41 of an integer (the cdf carries
+// <= 2^-49 of rounding); v = floor(u*T) and a 32-bit view f of the fraction come from (r >> 32) * T.
+// Byte k of D = (0x80 + v) - c_k keeps bit 7 iff c_k <= v; the chosen bin is the first k with c_k > v and
+// removing one unit there lowers every prefix sum from k on by one: C += (flags >> 7) - 0x01010101.
+// If f is within a wide margin of 0 or 2^32 the literal fp64 path decides instead (DESIGN.md "choice").
 template <bool LITERAL>
-__device__ __forceinline__ void sort_material(Env &e, const double acc_sorter[4])
+__device__ __forceinline__ void draw_units(Pcg &rng, uint32_t &C, int &rem)
 {
-    int l[4] = {e.sort[0], e.sort[1], e.sort[2], e.sort[3]};
-    int tr[4] = {0, 0, 0, 0}, fa[4] = {0, 0, 0, 0};
-    int st = 0, rem = 0;
-    for (;;) {
-        while (rem == 0 && st < 4) {
-            int target = sel4(l, st);
-            double prod = (double)target * sel4d(acc_sorter, st);
-            int t = (int)rint(prod); // int(round(np.float64)) : half to even (env_super.py:539)
-            int f = target - t;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                if (k == st) {
-                    tr[k] = t;
-                    fa[k] = f;
-                    l[k] = f;
-                }
-            }
-            rem = f;
-            ++st;
-        }
-        if (rem <= 0) break; // st == 4 and nothing left to draw (a negative count draws nothing)
-        int total = l[0] + l[1] + l[2] + l[3];
-        if (total == 0) { // env_super.py:557-559
+    while (rem > 0) {
+        pcg_advance(rng);
+        const uint32_t T = C >> 24;
+        if (T == 0u) { // env_super.py:557-559 (unreachable: the pool holds this station's own units)
             rem = 0;
-            continue;
+            break;
         }
-        uint64_t r = pcg_next64(e.rng);
-        int sel = choice4(l, total, r, LITERAL);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) l[k] -= (k == sel) ? 1 : 0;
+        uint32_t flags; // bit 7 of byte k set iff bin k is passed over (c_k <= v)
+        bool literal = LITERAL;
+        if (!LITERAL) {
+            const uint64_t prod = mad64(pcg_output_hi32(rng), T, 0ull);
+            const uint32_t f = (uint32_t)prod;
+            const uint32_t v = (uint32_t)(prod >> 32);
+            flags = (((v * 0x01010101u) | 0x80808080u) - C) & 0x00808080u;
+            literal = (f + 0x200u) < 0x210u; // f < 16 or f >= 2^32 - 512
+        }
+        if (literal) {
+            const int sel = choice4_literal(C, pcg_output(rng));
+            flags = sel == 0 ? 0u : (sel == 1 ? 0x00000080u : (sel == 2 ? 0x00008080u : 0x00808080u));
+        }
+        C += (flags >> 7) + 0xFEFEFEFFu; // - 0x01010101 on the bins from the chosen one on
         --rem;
     }
-    e.ce += l[0] + l[1] + l[2] + l[3];
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        e.ct[m] += tr[m];
-        e.cf[m] += fa[m];
+}
+
+// station I: true = rint(target * acc), false = target - true, leftover[I] = false (env_super.py:535-546)
+template <int I>
+__device__ __forceinline__ void station_split(Env &e, uint32_t &C, const double acc_sorter[4], int &rem)
+{
+    const uint32_t hi_b = (C >> (8 * I)) & 0xFFu;
+    const uint32_t lo_b = I == 0 ? 0u : ((C >> (8 * (I > 0 ? I - 1 : 0))) & 0xFFu);
+    const uint32_t target = hi_b - lo_b;
+    // int(round(np.int64 * float)) : half to even (env_super.py:539)
+    const uint32_t t = (uint32_t)(int)rint((double)target * acc_sorter[I]);
+    rem = (int)(target - t);
+    C -= t * (0x01010101u << (8 * I));
+    e.ct[I] += (int)t;
+    e.cf[I] += rem;
+}
+
+// Stations are walked in the reference's order.  Stations I and I+1 share one draw loop: a lane whose
+// station I has nothing to redistribute (accuracy 1.0 after the boost) starts station I+1 at once, so a
+// wave runs max(f_I, f_{I+1}) iterations instead of f_I + f_{I+1} when its lanes sit in different modes.
+template <bool LITERAL, int I>
+__device__ __forceinline__ void station_pair(Env &e, uint32_t &C, const double acc_sorter[4])
+{
+    int rem;
+    station_split<I>(e, C, acc_sorter, rem);
+    const bool early = rem == 0;
+    if (early) station_split<I + 1>(e, C, acc_sorter, rem);
+    draw_units<LITERAL>(e.rng, C, rem);
+    if (!early) {
+        station_split<I + 1>(e, C, acc_sorter, rem);
+        draw_units<LITERAL>(e.rng, C, rem);
     }
+}
+
+template <bool LITERAL>
+__device__ __forceinline__ void sort_material(Env &e, uint32_t sorting_word, const double acc_sorter[4])
+{
+    uint32_t C = sorting_word * 0x01010101u; // prefix sums of current_material_sorting
+    station_pair<LITERAL, 0>(e, C, acc_sorter);
+    station_pair<LITERAL, 2>(e, C, acc_sorter);
+    e.ce += (int)(C >> 24); // env_super.py:579,597
 }
 
 // buffered uint32 of PCG64 (pcg64.h pcg64_next32)
@@ -518,20 +582,15 @@ __device__ __forceinline__ int sample_masked_press_action(Env &e, const Params &
     return select_kth_bit(bits, (int)(m >> 32));
 }
 
-struct BaleCell {
-    uint32_t count, sum, last_size, last_q;
-};
-
-// env_super.py:661-687 press_bale on the O(1) ledger summary
-__device__ __forceinline__ void press_bale(uint4 *__restrict__ planes, long long n_pad, long long i, const Params &P,
-                                           int mat, int n, int q100)
+// env_super.py:661-687 press_bale on the O(1) ledger summary {count, sum, last_size, last_q}
+__device__ __forceinline__ void press_bale(uint4 *cell, int balesize, double rem_thr, int n, int q100)
 {
-    uint4 *cell = &planes[(long long)(PL_BALE0 + mat) * n_pad + i];
     uint4 c = *cell;
-    double q = (double)q100 / 100.0;   // the stored quality round(x, 2)
+    double q = (double)q100 / 100.0;          // the stored quality round(x, 2)
     uint32_t qi = (uint32_t)(int)(q * 100.0); // int(q*100) truncates (0.29 -> 28)
-    uint32_t S = (uint32_t)P.balesize;
-    uint32_t full = (uint32_t)n / S, rem = (uint32_t)n % S;
+    uint32_t S = (uint32_t)balesize;
+    uint32_t full = (uint32_t)floor((double)n / (double)S); // exact for int32 operands
+    uint32_t rem = (uint32_t)n - full * S;
     if (full > 0) {
         c.x += full;
         c.y += full * S;
@@ -539,7 +598,7 @@ __device__ __forceinline__ void press_bale(uint4 *__restrict__ planes, long long
         c.w = qi;
     }
     if (rem > 0) {
-        if ((double)rem > (double)S * P.rem_thr) {
+        if ((double)rem > (double)S * rem_thr) {
             c.x += 1;
             c.y += rem;
             c.z = rem;
@@ -557,16 +616,24 @@ __device__ __forceinline__ void press_bale(uint4 *__restrict__ planes, long long
     *cell = c;
 }
 
+// where the bale ledger of this lane lives: global planes (single-step kernel) or an LDS copy
+// (rollout kernel: no global load may sit in the step loop, its vmcnt wait would drain the output stores)
+struct BaleRef {
+    uint4 *base;        // cell (m) at base[m * stride]
+    long long stride;
+    __device__ __forceinline__ uint4 *cell(int m) const { return base + (long long)m * stride; }
+};
+
 // env_super.py:626-640 press_action_rules = check_press_status (:642-659) then use_press (:722-769)
-__device__ __forceinline__ void press_action_rules(Env &e, const Params &P, int press_action,
-                                                   uint4 *__restrict__ planes, long long i)
+__device__ __forceinline__ void press_action_rules(Env &e, const Params &P, const int *press_time, int press_action,
+                                                   const BaleRef &bales)
 {
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
         if (e.timer[p] > 0) {
             e.timer[p] -= 1;
             if (e.timer[p] == 0) {
-                if (P.track_bales) press_bale(planes, P.n_pad, i, P, e.pmat[p], e.pn[p], e.q100[p]);
+                if (P.track_bales) press_bale(bales.cell(e.pmat[p]), P.balesize, P.rem_thr, e.pn[p], e.q100[p]);
                 e.pmat[p] = 0xFF;
                 e.pn[p] = 0;
                 e.q100[p] = 0;
@@ -574,86 +641,123 @@ __device__ __forceinline__ void press_action_rules(Env &e, const Params &P, int 
         }
     }
     if (press_action == 0) return;
-    int p = press_action <= 5 ? 0 : 1;
-    int mat = (press_action - 1) % 5;
-    if (e.timer[p] > 0) return; // busy: no state change (env_super.py:725-733)
+    int p, mat;
+    decode_press_action(press_action, p, mat);
+    const int tm = p ? e.timer[1] : e.timer[0];
+    if (tm > 0) return; // busy: no state change (env_super.py:725-733)
     int total = e.ce, tru = 0; // container E: quality 0 (env_super.py:755-757)
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
         if (mat == m) {
             total = e.ct[m] + e.cf[m];
             tru = e.ct[m];
-        }
-    }
-    e.lps = 1;
-    e.lpa = total;
-    int q = 0;
-    if (mat < 4 && total > 0) q = (int)rint(((double)tru / (double)total) * 100.0); // round(x,2) in hundredths
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        if (mat == m) {
             e.ct[m] = 0;
             e.cf[m] = 0;
         }
     }
     if (mat == 4) e.ce = 0;
-    e.timer[p] = P.press_time[p];
-    e.pmat[p] = mat;
-    e.pn[p] = total;
-    e.q100[p] = q;
+    e.lps = 1;
+    e.lpa = total;
+    int q = 0;
+    if (tru > 0) q = (int)rint(((double)tru / (double)total) * 100.0); // round(x, 2) in hundredths
+    const int pt = press_time[p];
+    if (p) {
+        e.timer[1] = pt;
+        e.pmat[1] = mat;
+        e.pn[1] = total;
+        e.q100[1] = q;
+    } else {
+        e.timer[0] = pt;
+        e.pmat[0] = mat;
+        e.pn[0] = total;
+        e.q100[0] = q;
+    }
 }
 
-// env_super.py:771-791 get_container_purity, per material, as round(., 2) doubles
-__device__ __forceinline__ void container_purity(const Env &e, const Params &P, double purity[4])
+// env_super.py:771-791 get_container_purity per material, in hundredths:
+// round(true/total, 2) = rint((true/total)*100)/100; [101] marks an empty container (purity = threshold)
+__device__ __forceinline__ void container_purity_k(const Env &e, int k[4])
 {
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
         int total = e.ct[m] + e.cf[m];
-        purity[m] = total > 0 ? round2((double)e.ct[m] / (double)total) : P.thr_r2[m];
+        int v = (int)rint(((double)e.ct[m] / (double)(total > 0 ? total : 1)) * 100.0);
+        k[m] = total > 0 ? v : 101;
     }
 }
 
-// env_super.py:963-1003 calculate_sorting_reward
-__device__ __forceinline__ double sorting_reward(const Params &P, const double purity[4])
+// LDS-resident tables (image built on the host with the reference's literal expressions).  Everything a
+// lane selects by a per-lane index lives here: an indexed read of kernel arguments would be a global
+// load, and any vmcnt wait inside the step loop also waits for the previous step's output stores.
+struct Tables {
+    const float *lvl;    // [capacity+1]  clip(float(L / capacity))                  env_super.py:339-344
+    const float *pdiff;  // [4][102]      clip(float(round(k/100 - thr, 2)))         env_super.py:212-227
+    const float *timer0; // [press_time+1] clip(float(t / press_time))               env_super.py:354-356
+    const float *timer1;
+    const double *tanh_s; // [401]        sorting reward by sum of purity hundredths env_super.py:963-1003
+    const double *eff;    // [S/2+1]      (1 - 4*(dist/S)) * bale_efficiency_factor  env_super.py:1058-1062
+    const uint32_t *pat;  // [3][kPatStride] per stage id, see kPatStride
+    const double *acc;    // [3][4]       clip(baseline + boost by mode 0 | 1 | none) env_super.py:499-509
+    const double *bonus;  // [4]          target_peaks[min(num_bales,3)] - bale_efficiency_factor  :1065-1069
+    const int *press_time; // [2]
+};
+
+__device__ __forceinline__ Tables tables_at(const uint32_t *base, const Params &P)
 {
-    double total = 0.0;
+    Tables t;
+    t.lvl = reinterpret_cast<const float *>(base + P.off_lvl);
+    t.pdiff = reinterpret_cast<const float *>(base + P.off_pdiff);
+    t.timer0 = reinterpret_cast<const float *>(base + P.off_timer0);
+    t.timer1 = reinterpret_cast<const float *>(base + P.off_timer1);
+    t.tanh_s = reinterpret_cast<const double *>(base + P.off_tanh);
+    t.eff = reinterpret_cast<const double *>(base + P.off_eff);
+    t.pat = base + P.off_pat;
+    t.acc = reinterpret_cast<const double *>(base + P.off_acc);
+    t.bonus = reinterpret_cast<const double *>(base + P.off_bonus);
+    t.press_time = reinterpret_cast<const int *>(base + P.off_ptime);
+    return t;
+}
+
+// env_super.py:963-1003 calculate_sorting_reward: tanh(((sum_m (purity_m - theta)) / 4 * 2) / T).
+// The four purities are hundredths, so the reward is tabulated by their integer sum (the literal
+// fp64 sum differs from the tabulated one by < 1e-15, far inside the 1e-6 reward tolerance).
+__device__ __forceinline__ double sorting_reward(const Params &P, const Tables &tb, const int k[4])
+{
+    int s = 0;
 #pragma unroll
-    for (int m = 0; m < 4; ++m) total = total + (purity[m] - P.theta);
-    double state_based = (total / 4.0) * 2.0;
-    return tanh(state_based / P.temperature);
+    for (int m = 0; m < 4; ++m) s += (k[m] == 101) ? P.k_thr[m] : k[m];
+    return tb.tanh_s[s];
 }
 
 // env_super.py:1006-1080 calculate_press_reward
-__device__ __forceinline__ double press_reward(Env &e, const Params &P)
+__device__ __forceinline__ double press_reward(Env &e, const Params &P, const Tables &tb)
 {
-    double cap = (double)P.capacity;
-    double max_pen = 0.0;
-    bool catastrophic = false;
+    bool any_cat = false, any_sev = false, any_mild = false;
     int total_level = 0;
 #pragma unroll
     for (int m = 0; m < 5; ++m) {
         int lvl = level_of(e, m);
         total_level += lvl;
-        double fill = (double)lvl / cap;
-        if (fill > 1.0)
-            catastrophic = true;
-        else if (fill > 0.95)
-            max_pen = fmin(max_pen, P.pen_sev);
-        else if (fill > 0.90)
-            max_pen = fmin(max_pen, P.pen_mild);
+        bool cat = lvl > P.capacity;                  // fill_ratio > 1.0
+        bool sev = !cat && lvl > P.thr_sev;           // elif fill_ratio > 0.95
+        bool mild = !cat && !sev && lvl > P.thr_mild; // elif fill_ratio > 0.90
+        any_cat |= cat;
+        any_sev |= sev;
+        any_mild |= mild;
     }
-    if (catastrophic) return P.pen_cat;
+    if (any_cat) return P.pen_cat;
+    double max_pen = 0.0;
+    if (any_sev) max_pen = fmin(max_pen, P.pen_sev);
+    if (any_mild) max_pen = fmin(max_pen, P.pen_mild);
     if (max_pen < 0.0) return max_pen;
     double state_reward = ((double)total_level / (double)(5 * P.capacity)) * P.max_state_reward;
     double action_reward = 0.0;
     if (e.lps) {
-        int S = P.balesize;
-        int nb = e.lpa / S, rem = e.lpa % S;
+        const int S = P.balesize;
+        int nb = (int)floor((double)e.lpa / (double)S); // exact for int32 operands
+        int rem = e.lpa - nb * S;
         int dist = rem < S - rem ? rem : S - rem;
-        double eff = (1.0 - 4.0 * ((double)dist / (double)S)) * P.bef;
-        double peak = nb <= 0 ? 0.0 : (nb == 1 ? 1.0 / 3.0 : (nb == 2 ? 2.0 / 3.0 : 1.0));
-        double bonus = peak - P.bef;
-        action_reward = eff + bonus;
+        action_reward = tb.eff[dist] + tb.bonus[nb < 0 ? 0 : (nb > 3 ? 3 : nb)];
         e.lps = 0;
         e.lpa = 0;
     }
@@ -664,33 +768,38 @@ __device__ __forceinline__ double press_reward(Env &e, const Params &P)
 __device__ __forceinline__ float clip_f(float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
 // env_super.py:306-325 get_sort_obs -> o[0..12]
-__device__ __forceinline__ void sort_obs(const Env &e, const Params &P, const double purity[4], float *o)
+__device__ __forceinline__ void sort_obs(const Env &e, const Params &P, const Tables &tb, const int k[4], float *o)
 {
-    int total = e.belt[0] + e.belt[1] + e.belt[2] + e.belt[3];
-    o[0] = clip_f((float)((double)total / 100.0), -1.0f, 1.0f); // belt_occupancy = last input_occupancy
-#pragma unroll
-    for (int m = 0; m < 4; ++m)
-        o[1 + m] = total > 0 ? clip_f((float)((double)e.belt[m] / (double)total), -1.0f, 1.0f) : 0.0f;
+    const uint32_t *rec = tb.pat + e.st_belt * kPatStride;
+    o[0] = __uint_as_float(rec[1]); // belt_occupancy = the input occupancy of the batch that is now on the belt
+    const float4 prop = *reinterpret_cast<const float4 *>(rec + 4);
+    o[1] = prop.x;
+    o[2] = prop.y;
+    o[3] = prop.z;
+    o[4] = prop.w;
 #pragma unroll
     for (int m = 0; m < 4; ++m) o[5 + m] = clip_f((float)e.acc[m], -1.0f, 1.0f);
 #pragma unroll
-    for (int m = 0; m < 4; ++m) o[9 + m] = clip_f((float)round2(purity[m] - P.thr[m]), -1.0f, 1.0f);
+    for (int m = 0; m < 4; ++m) o[9 + m] = tb.pdiff[m * kPdiffStride + k[m]];
 }
 
 // env_super.py:327-359 get_press_obs -> o[0..15]
-__device__ __forceinline__ void press_obs(const Env &e, const Params &P, float *o)
+__device__ __forceinline__ void press_obs(const Env &e, const Params &P, const Tables &tb, float *o)
 {
-    double cap = (double)P.capacity;
 #pragma unroll
     for (int m = 0; m < 5; ++m) {
-        float v = clip_f((float)((double)level_of(e, m) / cap), 0.0f, 1.0f);
+        int lvl = level_of(e, m);
+        float v = tb.lvl[lvl < P.capacity ? lvl : P.capacity];
         o[m] = v;
         o[5 + m] = v;
     }
-#pragma unroll
-    for (int m = 0; m < 4; ++m) o[10 + m] = clip_f((float)((double)e.sort[m] / (double)P.stage_capacity), 0.0f, 1.0f);
-#pragma unroll
-    for (int p = 0; p < 2; ++p) o[14 + p] = clip_f((float)((double)e.timer[p] / (double)P.press_time[p]), 0.0f, 1.0f);
+    const float4 frac = *reinterpret_cast<const float4 *>(tb.pat + e.st_sort * kPatStride + 8);
+    o[10] = frac.x;
+    o[11] = frac.y;
+    o[12] = frac.z;
+    o[13] = frac.w;
+    o[14] = tb.timer0[e.timer[0]];
+    o[15] = tb.timer1[e.timer[1]];
 }
 
 template <int KIND>
@@ -709,15 +818,15 @@ struct Dims<3> {
 };
 
 template <int KIND>
-__device__ __forceinline__ void env_obs(const Env &e, const Params &P, const double purity[4], float *o)
+__device__ __forceinline__ void env_obs(const Env &e, const Params &P, const Tables &tb, const int k[4], float *o)
 {
     if (KIND == 1) {
-        sort_obs(e, P, purity, o);
+        sort_obs(e, P, tb, k, o);
     } else if (KIND == 2) {
-        press_obs(e, P, o);
+        press_obs(e, P, tb, o);
     } else {
-        sort_obs(e, P, purity, o);
-        press_obs(e, P, o + 13);
+        sort_obs(e, P, tb, k, o);
+        press_obs(e, P, tb, o + 13);
     }
 }
 
@@ -729,18 +838,16 @@ __device__ __forceinline__ int unseeded_gen2(const Env &e)
     return (int)(h & 1ull); // 1 -> first pattern key is 2
 }
 
-// env_super.py:365-420 reset (state part; streams are handled by the caller)
+// env_super.py:365-420 reset (state part; streams and episode count are handled by the caller)
 __device__ __forceinline__ void reset_episode_state(Env &e, const Params &P)
 {
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
         e.ct[m] = 0;
         e.cf[m] = 0;
-        e.in[m] = 0;
-        e.belt[m] = 0;
-        e.sort[m] = 0;
         e.acc[m] = P.base_acc[m];
     }
+    e.st_in = e.st_belt = e.st_sort = 0;
     e.ce = 0;
     e.pn[0] = e.pn[1] = 0;
     e.lpa = 0;
@@ -754,10 +861,10 @@ __device__ __forceinline__ void reset_episode_state(Env &e, const Params &P)
     e.step = 0;
 }
 
-__device__ __forceinline__ void clear_bales(uint4 *__restrict__ planes, long long n_pad, long long i)
+__device__ __forceinline__ void clear_bales(const BaleRef &bales)
 {
 #pragma unroll
-    for (int m = 0; m < 5; ++m) planes[(long long)(PL_BALE0 + m) * n_pad + i] = make_uint4(0, 0, 0, 0);
+    for (int m = 0; m < 5; ++m) *bales.cell(m) = make_uint4(0, 0, 0, 0);
 }
 
 struct StepResult {
@@ -766,35 +873,28 @@ struct StepResult {
 };
 
 // One env transition: env_1_sort.py:97-154 / env_2_press.py:88-165 / env_monolith.py:109-284.
-// `purity` returns the post-step container purities for the observation.
+// `k` returns the post-step container purities (hundredths) for the observation.
 template <int KIND, bool NOISE, bool LITERAL>
-__device__ __forceinline__ StepResult env_step(Env &e, const Params &P, int action, int sort_mode_in, uint32_t flags,
-                                               uint4 *__restrict__ planes, long long i, double purity[4])
+__device__ __forceinline__ StepResult env_step(Env &e, const Params &P, const Tables &tb, int action, int sort_mode_in,
+                                               uint32_t flags, const BaleRef &bales, int k[4])
 {
     const bool unmasked = (flags & 1u) != 0;
     const bool check_overflow = (flags & 2u) != 0;
 
     // input_action_rules draws rng_input.integers(60,81) and discards it (env_super.py:911-922, :433);
     // that stream is never observed, so it is not carried.
-    update_environment(e, P);
+    update_environment(e);
 
     int sort_mode, press_action = 0;
     bool run_press_rules = true;
     if (KIND == 1) {
         sort_mode = action;
     } else if (KIND == 2) {
-        if (sort_mode_in >= 0) {
-            sort_mode = sort_mode_in;
-        } else { // env_super.py:469-482 sorting_rules on the post-flow belt
-            int total = e.belt[0] + e.belt[1] + e.belt[2] + e.belt[3];
-            double pr[4];
-#pragma unroll
-            for (int m = 0; m < 4; ++m) pr[m] = total > 0 ? (double)e.belt[m] / (double)total : 0.0;
-            sort_mode = (pr[0] + pr[2] > pr[1] + pr[3]) ? 0 : 1;
-        }
+        // the sorting agent's decision, else sorting_rules() on the post-flow belt (env_super.py:469-482)
+        sort_mode = sort_mode_in >= 0 ? sort_mode_in : (int)tb.pat[e.st_belt * kPatStride + 2];
         press_action = action;
     } else {
-        sort_mode = action / 11;
+        sort_mode = action >= 11 ? 1 : 0;
         press_action = action - 11 * sort_mode;
         // env_monolith.py:132-138: validated at decode time (pre-sort levels); an invalid action
         // skips press_action_rules altogether, so the timers do not tick this step
@@ -802,8 +902,8 @@ __device__ __forceinline__ StepResult env_step(Env &e, const Params &P, int acti
     }
 
     double acc_sorter[4];
-    update_accuracy<NOISE>(e, P, sort_mode, acc_sorter);
-    sort_material<LITERAL>(e, acc_sorter);
+    update_accuracy<NOISE>(e, P, tb.acc, sort_mode, acc_sorter);
+    sort_material<LITERAL>(e, tb.pat[e.st_sort * kPatStride], acc_sorter);
 
     if (KIND == 1) {
         press_action = sample_masked_press_action(e, P); // env_1_sort.py:125-126 (mask before the tick)
@@ -811,29 +911,28 @@ __device__ __forceinline__ StepResult env_step(Env &e, const Params &P, int acti
         // env_2_press.py:125-138: validated against post-sort levels; the timers still tick
         if (unmasked && !press_action_valid(e, P, press_action)) press_action = 0;
     }
-    if (run_press_rules) press_action_rules(e, P, press_action, planes, i);
+    if (run_press_rules) press_action_rules(e, P, tb.press_time, press_action, bales);
 
     StepResult r;
+    container_purity_k(e, k);
     if (check_overflow) { // env_super.py:900-905 + the variants' early return
         bool over = false;
 #pragma unroll
         for (int m = 0; m < 5; ++m) over = over || (level_of(e, m) > P.capacity);
         if (over) {
-            container_purity(e, P, purity);
             e.step += 1;
             r.reward = P.overflow_pen;
             r.done = 1;
             return r;
         }
     }
-    container_purity(e, P, purity);
     if (KIND == 1) {
-        r.reward = sorting_reward(P, purity);
+        r.reward = sorting_reward(P, tb, k);
     } else if (KIND == 2) {
-        r.reward = press_reward(e, P);
+        r.reward = press_reward(e, P, tb);
     } else {
-        double rs = sorting_reward(P, purity);
-        double rp = press_reward(e, P);
+        double rs = sorting_reward(P, tb, k);
+        double rp = press_reward(e, P, tb);
         r.reward = rs + rp;
     }
     e.step += 1;

@@ -12,68 +12,98 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <vector>
 
 using namespace mse;
 
 // ==========================================================================================
-// output staging: rows computed one-per-lane are transposed through LDS so that global stores
-// are 16 B per lane and contiguous across the workgroup (obs rows are 52/64/116 B long).
+// LDS: [obs staging f32 256 x D][mask staging u8 256 x A (+pad)][tables]   (all dynamic, 16-B aligned base)
+// Rows computed one-per-lane are transposed through LDS so that global stores are 16 B per lane and
+// contiguous across the workgroup (obs rows are 52/64/116 B long).  The barriers wait for LDS only:
+// a __syncthreads() would also drain the global stores of the previous step (vmcnt(0)), which was 37 %
+// of the wave time in the first profile (profiles/r01/v1_baseline_summary.json).
 // ==========================================================================================
-template <int D>
-__device__ __forceinline__ void stage_rows_f32(float *lds, const float *row, float *gout, int n_valid, int tid)
-{
-#pragma unroll
-    for (int j = 0; j < D; ++j) lds[tid * D + j] = row[j]; // odd D: conflict-free; D=16: 16-way on 4 B stores
-    __syncthreads();
-    const int total = n_valid * D;
-    if ((reinterpret_cast<uintptr_t>(gout) & 15u) == 0) {
-        const int nvec = total >> 2;
-        const float4 *src = reinterpret_cast<const float4 *>(lds);
-        float4 *dst = reinterpret_cast<float4 *>(gout);
-        for (int v = tid; v < nvec; v += kBlock) dst[v] = src[v];
-        for (int k = (nvec << 2) + tid; k < total; k += kBlock) gout[k] = lds[k];
-    } else {
-        for (int k = tid; k < total; k += kBlock) gout[k] = lds[k];
-    }
-    __syncthreads();
-}
-
-template <int A>
-__device__ __forceinline__ void stage_rows_mask(uint8_t *lds, uint32_t bits, uint8_t *gout, int n_valid, int tid)
-{
-#pragma unroll
-    for (int j = 0; j < A; ++j) lds[tid * A + j] = (uint8_t)((bits >> j) & 1u);
-    __syncthreads();
-    const int total = n_valid * A;
-    if ((reinterpret_cast<uintptr_t>(gout) & 15u) == 0) {
-        const int nvec = total >> 4;
-        const uint4 *src = reinterpret_cast<const uint4 *>(lds);
-        uint4 *dst = reinterpret_cast<uint4 *>(gout);
-        for (int v = tid; v < nvec; v += kBlock) dst[v] = src[v];
-        for (int k = (nvec << 4) + tid; k < total; k += kBlock) gout[k] = lds[k];
-    } else {
-        for (int k = tid; k < total; k += kBlock) gout[k] = lds[k];
-    }
-    __syncthreads();
-}
+extern __shared__ uint4 mse_dyn_lds[];
 
 template <int KIND>
-struct alignas(16) StageLds {
-    float obs[kBlock * Dims<KIND>::D];
-    uint8_t mask[kBlock * Dims<KIND>::A + 16];
+struct LdsLayout {
+    static constexpr int D = Dims<KIND>::D, A = Dims<KIND>::A;
+    static constexpr int obs_bytes = kBlock * D * 4;
+    static constexpr int mask_bytes = (kBlock * A + 15) / 16 * 16;
+    static constexpr int bale_offset = obs_bytes + mask_bytes;    // [5][kBlock] uint4, rollout kernel only
+    static constexpr int bale_bytes = 5 * kBlock * 16;
+    static constexpr int table_offset_step = bale_offset;         // k_step keeps the ledger in global memory
+    static constexpr int table_offset_rollout = bale_offset + bale_bytes;
 };
 
-// auto-reset of a finished episode inside the step (reset(seed=None) semantics: streams continue)
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+__device__ __forceinline__ void load_tables_to_lds(uint32_t *dst, const uint32_t *__restrict__ src, int words, int tid)
+{
+    for (int w = tid; w < words; w += kBlock) dst[w] = src[w];
+    __syncthreads();
+}
+
+// write this lane's rows, then the workgroup streams the tile out; gout_* point at the tile's first row
 template <int KIND>
-__device__ __forceinline__ void auto_reset_env(Env &e, const Params &P, uint4 *__restrict__ planes, long long i,
-                                               double purity[4])
+__device__ __forceinline__ void stage_and_store(uint8_t *lds_base, const float *o, uint32_t mbits, float *gobs,
+                                                uint8_t *gmask, int n_valid, int tid)
+{
+    constexpr int D = Dims<KIND>::D, A = Dims<KIND>::A;
+    float *lobs = reinterpret_cast<float *>(lds_base);
+    uint8_t *lmask = lds_base + LdsLayout<KIND>::obs_bytes;
+    if (gobs != nullptr) {
+#pragma unroll
+        for (int j = 0; j < D; ++j) lobs[tid * D + j] = o[j];
+    }
+    if (gmask != nullptr) {
+        // rows are A bytes (A even): two mask bytes per 16-bit LDS store
+        uint16_t *row = reinterpret_cast<uint16_t *>(lmask + tid * A);
+#pragma unroll
+        for (int j = 0; j < A / 2; ++j)
+            row[j] = (uint16_t)(((mbits >> (2 * j)) & 1u) | (((mbits >> (2 * j + 1)) & 1u) << 8));
+        if (A & 1) lmask[tid * A + A - 1] = (uint8_t)((mbits >> (A - 1)) & 1u);
+    }
+    lds_barrier();
+    if (gobs != nullptr) {
+        const int total = n_valid * D;
+        if ((reinterpret_cast<uintptr_t>(gobs) & 15u) == 0) {
+            const int nvec = total >> 2;
+            const float4 *src = reinterpret_cast<const float4 *>(lobs);
+            float4 *dst = reinterpret_cast<float4 *>(gobs);
+            for (int v = tid; v < nvec; v += kBlock) dst[v] = src[v];
+            for (int q = (nvec << 2) + tid; q < total; q += kBlock) gobs[q] = lobs[q];
+        } else {
+            for (int q = tid; q < total; q += kBlock) gobs[q] = lobs[q];
+        }
+    }
+    if (gmask != nullptr) {
+        const int total = n_valid * A;
+        if ((reinterpret_cast<uintptr_t>(gmask) & 15u) == 0) {
+            const int nvec = total >> 4;
+            const uint4 *src = reinterpret_cast<const uint4 *>(lmask);
+            uint4 *dst = reinterpret_cast<uint4 *>(gmask);
+            for (int v = tid; v < nvec; v += kBlock) dst[v] = src[v];
+            for (int q = (nvec << 4) + tid; q < total; q += kBlock) gmask[q] = lmask[q];
+        } else {
+            for (int q = tid; q < total; q += kBlock) gmask[q] = lmask[q];
+        }
+    }
+    lds_barrier(); // the tile may be overwritten after this
+}
+
+// auto-reset of a finished episode inside the step (reset(seed=None) semantics: streams continue)
+__device__ __forceinline__ void auto_reset_env(Env &e, const Params &P, const BaleRef &bales, int k[4])
 {
     e.gen2 = unseeded_gen2(e);
     e.episode += 1u;
     reset_episode_state(e, P);
-    if (P.track_bales) clear_bales(planes, P.n_pad, i);
+    if (P.track_bales) clear_bales(bales);
 #pragma unroll
-    for (int m = 0; m < 4; ++m) purity[m] = P.thr_r2[m];
+    for (int m = 0; m < 4; ++m) k[m] = 101; // empty containers
 }
 
 // ==========================================================================================
@@ -81,6 +111,7 @@ __device__ __forceinline__ void auto_reset_env(Env &e, const Params &P, uint4 *_
 // ==========================================================================================
 template <int KIND, bool NOISE, bool LITERAL>
 __global__ __launch_bounds__(kBlock) void k_step(Params P, uint4 *__restrict__ planes,
+                                                 const uint32_t *__restrict__ table_image,
                                                  const int *__restrict__ action, const int *__restrict__ sort_mode,
                                                  uint32_t flags, float *__restrict__ obs_out,
                                                  float *__restrict__ reward_out, double *__restrict__ reward64_out,
@@ -89,11 +120,15 @@ __global__ __launch_bounds__(kBlock) void k_step(Params P, uint4 *__restrict__ p
                                                  unsigned long long *__restrict__ err_count)
 {
     constexpr int D = Dims<KIND>::D, A = Dims<KIND>::A;
-    __shared__ StageLds<KIND> lds;
+    uint8_t *lds = reinterpret_cast<uint8_t *>(mse_dyn_lds);
+    uint32_t *ltab = reinterpret_cast<uint32_t *>(lds + LdsLayout<KIND>::table_offset_step);
     const int tid = threadIdx.x;
+    load_tables_to_lds(ltab, table_image, P.table_words, tid);
+    const Tables tb = tables_at(ltab, P);
     const long long row0 = (long long)blockIdx.x * kBlock;
     const long long i = row0 + tid;
     const bool live = i < P.n;
+    const BaleRef bales{planes + (long long)PL_BALE0 * P.n_pad + i, P.n_pad};
     float o[D];
     uint32_t mbits = 0;
 #pragma unroll
@@ -101,38 +136,39 @@ __global__ __launch_bounds__(kBlock) void k_step(Params P, uint4 *__restrict__ p
 
     if (live) {
         Env e;
-        load_env<KIND, NOISE>(e, planes, P.n_pad, i);
+        load_env<KIND, NOISE>(e, planes, P, i);
         int a = action[i];
         if (a < 0 || a >= A) {
             atomicAdd(err_count, 1ull);
             a = 0;
         }
         int sm = (KIND == 2 && sort_mode != nullptr) ? sort_mode[i] : -1;
-        double purity[4];
-        StepResult r = env_step<KIND, NOISE, LITERAL>(e, P, a, sm, flags, planes, i, purity);
-        env_obs<KIND>(e, P, purity, o);
+        int k[4];
+        StepResult r = env_step<KIND, NOISE, LITERAL>(e, P, tb, a, sm, flags, bales, k);
+        env_obs<KIND>(e, P, tb, k, o);
         if (r.done && P.auto_reset) {
             if (terminal_obs_out != nullptr) {
 #pragma unroll
                 for (int j = 0; j < D; ++j) terminal_obs_out[i * D + j] = o[j];
             }
-            auto_reset_env<KIND>(e, P, planes, i, purity);
-            env_obs<KIND>(e, P, purity, o);
+            auto_reset_env(e, P, bales, k);
+            env_obs<KIND>(e, P, tb, k, o);
         }
         mbits = action_mask_bits<KIND>(e, P);
-        store_env<KIND, NOISE>(e, planes, P.n_pad, i, false);
+        store_env<KIND, NOISE>(e, planes, P, i, false);
         if (reward_out != nullptr) reward_out[i] = (float)r.reward;
         if (reward64_out != nullptr) reward64_out[i] = r.reward;
         if (done_out != nullptr) done_out[i] = (uint8_t)r.done;
     }
     long long rem = P.n - row0;
     const int n_valid = rem >= kBlock ? kBlock : (rem > 0 ? (int)rem : 0);
-    if (obs_out != nullptr) stage_rows_f32<D>(lds.obs, o, obs_out + row0 * D, n_valid, tid);
-    if (mask_out != nullptr) stage_rows_mask<A>(lds.mask, mbits, mask_out + row0 * A, n_valid, tid);
+    stage_and_store<KIND>(lds, o, mbits, obs_out ? obs_out + row0 * D : nullptr, mask_out ? mask_out + row0 * A : nullptr,
+                          n_valid, tid);
 }
 
 template <int KIND, bool NOISE, bool LITERAL>
-__global__ __launch_bounds__(kBlock) void k_rollout(Params P, uint4 *__restrict__ planes, int k_steps,
+__global__ __launch_bounds__(kBlock) void k_rollout(Params P, uint4 *__restrict__ planes,
+                                                    const uint32_t *__restrict__ table_image, int k_steps,
                                                     uint64_t policy_seed, uint64_t policy_t0,
                                                     const int *__restrict__ sort_mode, uint32_t flags,
                                                     int *__restrict__ actions_out, float *__restrict__ obs_out,
@@ -140,50 +176,68 @@ __global__ __launch_bounds__(kBlock) void k_rollout(Params P, uint4 *__restrict_
                                                     uint8_t *__restrict__ mask_out)
 {
     constexpr int D = Dims<KIND>::D, A = Dims<KIND>::A;
-    __shared__ StageLds<KIND> lds;
+    uint8_t *lds = reinterpret_cast<uint8_t *>(mse_dyn_lds);
+    uint32_t *ltab = reinterpret_cast<uint32_t *>(lds + LdsLayout<KIND>::table_offset_rollout);
+    uint4 *lbale = reinterpret_cast<uint4 *>(lds + LdsLayout<KIND>::bale_offset);
     const int tid = threadIdx.x;
     const long long row0 = (long long)blockIdx.x * kBlock;
-    const long long i = row0 + tid;
+    const long long i = row0 + tid; // i < n_pad always: the planes are padded to whole workgroups
     const bool live = i < P.n;
     long long rem = P.n - row0;
     const int n_valid = rem >= kBlock ? kBlock : (rem > 0 ? (int)rem : 0);
 
+    // the bale ledger of this workgroup's envs stays in LDS for the whole launch
+    const BaleRef bales{lbale + tid, kBlock};
+    if (P.track_bales) {
+#pragma unroll
+        for (int m = 0; m < 5; ++m) lbale[m * kBlock + tid] = planes[(long long)(PL_BALE0 + m) * P.n_pad + i];
+    }
+    load_tables_to_lds(ltab, table_image, P.table_words, tid);
+    const Tables tb = tables_at(ltab, P);
+
     Env e;
     int sm = -1;
     if (live) {
-        load_env<KIND, NOISE>(e, planes, P.n_pad, i);
+        load_env<KIND, NOISE>(e, planes, P, i);
         if (KIND == 2 && sort_mode != nullptr) sm = sort_mode[i];
     }
+    // every load has landed before the step loop: inside it there are only stores, which nothing waits for
+    __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
     float o[D];
 #pragma unroll
     for (int j = 0; j < D; ++j) o[j] = 0.0f;
 
-    for (int k = 0; k < k_steps; ++k) {
+    for (int s = 0; s < k_steps; ++s) {
         uint32_t mbits = 0;
-        const long long srow = (long long)k * P.n + row0;
+        const long long srow = (long long)s * P.n + row0;
         if (live) {
             // masked-uniform policy on the current state (env_monolith.py:152-158 with masking)
             uint32_t cur = action_mask_bits<KIND>(e, P);
             uint32_t cnt = (uint32_t)__popc(cur);
-            uint32_t rr = policy_u32(policy_seed, (uint64_t)(P.index_offset + i), policy_t0 + (uint64_t)k);
+            uint32_t rr = policy_u32(policy_seed, (uint64_t)(P.index_offset + i), policy_t0 + (uint64_t)s);
             int a = select_kth_bit(cur, (int)(((uint64_t)rr * cnt) >> 32));
-            double purity[4];
-            StepResult r = env_step<KIND, NOISE, LITERAL>(e, P, a, sm, flags, planes, i, purity);
-            if (r.done) auto_reset_env<KIND>(e, P, planes, i, purity);
-            env_obs<KIND>(e, P, purity, o);
+            int k[4];
+            StepResult r = env_step<KIND, NOISE, LITERAL>(e, P, tb, a, sm, flags, bales, k);
+            if (r.done) auto_reset_env(e, P, bales, k);
+            env_obs<KIND>(e, P, tb, k, o);
             mbits = action_mask_bits<KIND>(e, P);
-            if (actions_out != nullptr) actions_out[(long long)k * P.n + i] = a;
-            if (reward_out != nullptr) reward_out[(long long)k * P.n + i] = (float)r.reward;
-            if (done_out != nullptr) done_out[(long long)k * P.n + i] = (uint8_t)r.done;
+            if (actions_out != nullptr) actions_out[(long long)s * P.n + i] = a;
+            if (reward_out != nullptr) reward_out[(long long)s * P.n + i] = (float)r.reward;
+            if (done_out != nullptr) done_out[(long long)s * P.n + i] = (uint8_t)r.done;
         }
-        if (obs_out != nullptr) stage_rows_f32<D>(lds.obs, o, obs_out + srow * D, n_valid, tid);
-        if (mask_out != nullptr) stage_rows_mask<A>(lds.mask, mbits, mask_out + srow * A, n_valid, tid);
+        stage_and_store<KIND>(lds, o, mbits, obs_out ? obs_out + srow * D : nullptr,
+                              mask_out ? mask_out + srow * A : nullptr, n_valid, tid);
     }
-    if (live) store_env<KIND, NOISE>(e, planes, P.n_pad, i, false);
+    if (live) store_env<KIND, NOISE>(e, planes, P, i, false);
+    if (P.track_bales) {
+#pragma unroll
+        for (int m = 0; m < 5; ++m) planes[(long long)(PL_BALE0 + m) * P.n_pad + i] = lbale[m * kBlock + tid];
+    }
 }
 
 template <int KIND>
 __global__ __launch_bounds__(kBlock) void k_reset(Params P, uint4 *__restrict__ planes,
+                                                  const uint32_t *__restrict__ table_image,
                                                   const uint64_t *__restrict__ seeds,
                                                   const uint8_t *__restrict__ which, float *__restrict__ obs_out,
                                                   uint8_t *__restrict__ mask_out)
@@ -191,8 +245,9 @@ __global__ __launch_bounds__(kBlock) void k_reset(Params P, uint4 *__restrict__ 
     constexpr int D = Dims<KIND>::D, A = Dims<KIND>::A;
     const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
     if (i >= P.n) return;
+    const Tables tb = tables_at(table_image, P); // cold kernel: tables straight from global memory
     Env e;
-    load_env<1, true>(e, planes, P.n_pad, i); // every plane, whatever the env kind
+    load_env<1, true>(e, planes, P, i); // every plane, whatever the env kind
     const bool doit = which == nullptr || which[i] != 0;
     bool reseeded = false;
     if (doit) {
@@ -215,14 +270,14 @@ __global__ __launch_bounds__(kBlock) void k_reset(Params P, uint4 *__restrict__ 
             e.episode += 1u;
         }
         reset_episode_state(e, P);
-        clear_bales(planes, P.n_pad, i);
-        store_env<1, true>(e, planes, P.n_pad, i, reseeded);
+        clear_bales(BaleRef{planes + (long long)PL_BALE0 * P.n_pad + i, P.n_pad});
+        store_env<1, true>(e, planes, P, i, reseeded);
     }
     if (obs_out != nullptr) {
-        double purity[4];
-        container_purity(e, P, purity);
+        int k[4];
+        container_purity_k(e, k);
         float o[D];
-        env_obs<KIND>(e, P, purity, o);
+        env_obs<KIND>(e, P, tb, k, o);
 #pragma unroll
         for (int j = 0; j < D; ++j) obs_out[i * D + j] = o[j];
     }
@@ -241,7 +296,7 @@ __global__ __launch_bounds__(kBlock) void k_masks(Params P, const uint4 *__restr
     const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
     if (i >= P.n) return;
     Env e;
-    load_env<KIND, false>(e, planes, P.n_pad, i);
+    load_env<KIND, false>(e, planes, P, i);
     uint32_t bits = action_mask_bits<KIND>(e, P);
 #pragma unroll
     for (int j = 0; j < A; ++j) mask_out[i * A + j] = (uint8_t)((bits >> j) & 1u);
@@ -254,7 +309,7 @@ __global__ __launch_bounds__(kBlock) void k_sample(Params P, const uint4 *__rest
     const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
     if (i >= P.n) return;
     Env e;
-    load_env<KIND, false>(e, planes, P.n_pad, i);
+    load_env<KIND, false>(e, planes, P, i);
     uint32_t cur = action_mask_bits<KIND>(e, P);
     uint32_t cnt = (uint32_t)__popc(cur);
     uint32_t rr = policy_u32(policy_seed, (uint64_t)(P.index_offset + i), policy_t);
@@ -269,14 +324,15 @@ __global__ __launch_bounds__(kBlock) void k_get_state(Params P, const uint4 *__r
     const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
     if (i >= P.n) return;
     Env e;
-    load_env<1, true>(e, planes, P.n_pad, i);
+    load_env<1, true>(e, planes, P, i);
     if (I != nullptr) {
         long long *r = I + i * MSE_SNAP_INTS;
         for (int c = 0; c < MSE_SNAP_INTS; ++c) r[c] = 0;
+        const uint32_t w_in = stage_word(e.st_in, P), w_belt = stage_word(e.st_belt, P), w_sort = stage_word(e.st_sort, P);
         for (int m = 0; m < 4; ++m) {
-            r[0 + m] = e.in[m];
-            r[4 + m] = e.belt[m];
-            r[8 + m] = e.sort[m];
+            r[0 + m] = (w_in >> (8 * m)) & 0xFFu;
+            r[4 + m] = (w_belt >> (8 * m)) & 0xFFu;
+            r[8 + m] = (w_sort >> (8 * m)) & 0xFFu;
             r[12 + m] = e.ct[m];
             r[16 + m] = e.cf[m];
         }
@@ -319,23 +375,32 @@ __global__ __launch_bounds__(kBlock) void k_get_state(Params P, const uint4 *__r
     }
 }
 
+// Stage vectors must be one of {zeros, pattern 1, pattern 2} (the only values the generator emits);
+// anything else is counted in err_count and read as pattern 2.
 __global__ __launch_bounds__(kBlock) void k_set_state(Params P, uint4 *__restrict__ planes,
                                                       const long long *__restrict__ I, const double *__restrict__ Dd,
-                                                      const unsigned long long *__restrict__ R)
+                                                      const unsigned long long *__restrict__ R,
+                                                      unsigned long long *__restrict__ err_count)
 {
     const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
     if (i >= P.n) return;
     Env e;
-    load_env<1, true>(e, planes, P.n_pad, i);
+    load_env<1, true>(e, planes, P, i);
     if (I != nullptr) {
         const long long *r = I + i * MSE_SNAP_INTS;
+        uint32_t w[3] = {0, 0, 0};
         for (int m = 0; m < 4; ++m) {
-            e.in[m] = (int)r[0 + m];
-            e.belt[m] = (int)r[4 + m];
-            e.sort[m] = (int)r[8 + m];
+            w[0] |= ((uint32_t)r[0 + m] & 0xFFu) << (8 * m);
+            w[1] |= ((uint32_t)r[4 + m] & 0xFFu) << (8 * m);
+            w[2] |= ((uint32_t)r[8 + m] & 0xFFu) << (8 * m);
             e.ct[m] = (int)r[12 + m];
             e.cf[m] = (int)r[16 + m];
         }
+        for (int s = 0; s < 3; ++s)
+            if (w[s] != P.pat_word[0] && w[s] != P.pat_word[1] && w[s] != P.pat_word[2]) atomicAdd(err_count, 1ull);
+        e.st_in = stage_id(w[0], P);
+        e.st_belt = stage_id(w[1], P);
+        e.st_sort = stage_id(w[2], P);
         e.ce = (int)r[20];
         for (int p = 0; p < 2; ++p) {
             e.timer[p] = (int)r[21 + p];
@@ -365,7 +430,7 @@ __global__ __launch_bounds__(kBlock) void k_set_state(Params P, uint4 *__restric
         e.press_has = (int)w[16];
         e.press_uint = (uint32_t)w[17];
     }
-    store_env<1, true>(e, planes, P.n_pad, i, true);
+    store_env<1, true>(e, planes, P, i, true);
 }
 
 // ==========================================================================================
@@ -375,10 +440,12 @@ struct mse_env {
     Params P;
     mse_config cfg;
     uint4 *planes;
+    uint32_t *tables;            // device image of the lookup tables (build_tables)
     unsigned long long *err_count;
     int device;
     bool seeded;
     bool noise_on;
+    bool literal;                // evaluate every Generator.choice draw in literal fp64
     uint64_t policy_t;
 };
 
@@ -399,16 +466,154 @@ static int fail(int status, const std::string &msg)
 
 static bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+
+// ------------------------------------------------------------------------------------------
+// Lookup tables and per-pattern constants.  Every entry is the reference's own fp64 expression
+// evaluated on the host for each possible integer argument (this translation unit is compiled
+// with -ffp-contract=off), so a device lookup returns exactly what the reference computes.
+// ------------------------------------------------------------------------------------------
+static inline double host_round2(double x) { return std::nearbyint(x * 100.0) / 100.0; } // round(np.float64, 2)
+static inline float host_clip_f(float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+static int build_tables(const mse_config &c, Params &P, std::vector<uint32_t> &image, std::string &why)
+{
+    const int cap = c.container_capacity, S = c.bale_standard_size;
+    uint32_t pat_rec[3][kPatStride];
+    for (int k = 0; k < 3; ++k) {
+        uint32_t w = 0;
+        int sum = 0;
+        for (int m = 0; m < 4; ++m) {
+            // utils/input_generator.py:47: int(np.floor(ratio * batchsize)); id 0 = the empty stage after reset
+            int cnt = k == 0 ? 0 : (int)std::floor(c.pattern_ratio[k - 1][m] * (double)c.input_batch_size);
+            w |= (uint32_t)cnt << (8 * m);
+            sum += cnt;
+        }
+        if (k > 0 && sum != c.input_batch_size) {
+            why = "input_batch_size leaves a floor() remainder for a seasonal pattern: the generator's random "
+                  "remainder draws (utils/input_generator.py:50-55) are not on the restated path";
+            return MSE_ERR_UNSUPPORTED_CONFIG;
+        }
+        P.pat_word[k] = w;
+        auto f32_bits = [](float v) {
+            uint32_t u;
+            std::memcpy(&u, &v, 4);
+            return u;
+        };
+        pat_rec[k][0] = w;
+        // env_super.py:456 input_occupancy = round(sum/100, 2); get_sort_obs casts to f32 and clips to [-1,1]
+        pat_rec[k][1] = f32_bits(host_clip_f((float)((double)sum / 100.0), -1.0f, 1.0f));
+        pat_rec[k][3] = 0;
+        double pr[4];
+        for (int m = 0; m < 4; ++m) {
+            int cnt = (int)((w >> (8 * m)) & 0xFFu);
+            pr[m] = sum > 0 ? (double)cnt / (double)sum : 0.0;                                   // env_super.py:199-210
+            pat_rec[k][4 + m] = f32_bits(host_clip_f((float)pr[m], -1.0f, 1.0f));
+            pat_rec[k][8 + m] = f32_bits(host_clip_f((float)((double)cnt / (double)c.stage_capacity), 0.0f, 1.0f)); // :351
+        }
+        pat_rec[k][2] = (pr[0] + pr[2] > pr[1] + pr[3]) ? 0u : 1u;                               // env_super.py:479-482
+    }
+    if (P.pat_word[1] == P.pat_word[2] || P.pat_word[1] == 0 || P.pat_word[2] == 0) {
+        why = "the two seasonal patterns must give distinct, non-empty material counts";
+        return MSE_ERR_UNSUPPORTED_CONFIG;
+    }
+    // fill_ratio thresholds of calculate_press_reward as integer levels (env_super.py:1020-1027)
+    P.thr_sev = P.thr_mild = cap;
+    for (int L = cap; L >= 0; --L) {
+        double fill = (double)L / (double)cap;
+        if (fill > 0.95) P.thr_sev = L - 1;
+        if (fill > 0.90) P.thr_mild = L - 1;
+    }
+    double acc_rows[3][4]; // np.clip(acc + 0, 0, 1) for mode 0, mode 1, any other mode (env_super.py:499-509)
+    for (int m = 0; m < 4; ++m) {
+        P.k_thr[m] = (int)std::nearbyint(c.quality_threshold_r2[m] * 100.0);
+        if (P.k_thr[m] < 0 || P.k_thr[m] > 100) {
+            why = "quality thresholds must lie in [0, 1]";
+            return MSE_ERR_UNSUPPORTED_CONFIG;
+        }
+        const double lo = c.baseline_accuracy[m], hi = c.baseline_accuracy[m] + c.boost;
+        const double lo_c = lo < 0.0 ? 0.0 : (lo > 1.0 ? 1.0 : lo), hi_c = hi < 0.0 ? 0.0 : (hi > 1.0 ? 1.0 : hi);
+        acc_rows[0][m] = (m == 0 || m == 2) ? hi_c : lo_c;
+        acc_rows[1][m] = (m == 1 || m == 3) ? hi_c : lo_c;
+        acc_rows[2][m] = lo_c;
+    }
+    const double peaks[4] = {0.0, 1.0 / 3.0, 2.0 / 3.0, 1.0}; // env_super.py:1065
+
+    auto put_f32 = [&](float v) {
+        uint32_t u;
+        std::memcpy(&u, &v, 4);
+        image.push_back(u);
+    };
+    auto put_f64 = [&](double v) {
+        uint64_t u;
+        std::memcpy(&u, &v, 8);
+        image.push_back((uint32_t)u);
+        image.push_back((uint32_t)(u >> 32));
+    };
+    image.clear();
+    P.off_lvl = (int)image.size(); // env_super.py:339-344,359
+    for (int L = 0; L <= cap; ++L) put_f32(host_clip_f((float)((double)L / (double)cap), 0.0f, 1.0f));
+    P.off_pdiff = (int)image.size(); // env_super.py:212-227, 771-791, 325
+    for (int m = 0; m < 4; ++m) {
+        for (int k = 0; k <= 101; ++k) {
+            double purity = k <= 100 ? (double)k / 100.0 : c.quality_threshold_r2[m];
+            put_f32(host_clip_f((float)host_round2(purity - c.quality_threshold[m]), -1.0f, 1.0f));
+        }
+    }
+    P.off_timer0 = (int)image.size(); // env_super.py:354-356
+    for (int t = 0; t <= c.press_time[0]; ++t) put_f32(host_clip_f((float)((double)t / (double)c.press_time[0]), 0.0f, 1.0f));
+    P.off_timer1 = (int)image.size();
+    for (int t = 0; t <= c.press_time[1]; ++t) put_f32(host_clip_f((float)((double)t / (double)c.press_time[1]), 0.0f, 1.0f));
+    if (image.size() & 1u) image.push_back(0u); // 8-byte alignment of the f64 tables
+    P.off_tanh = (int)image.size(); // env_super.py:963-1003 by the sum s of the four purity hundredths
+    for (int s = 0; s <= 400; ++s) {
+        long double total = (long double)s / 100.0L - 4.0L * (long double)c.purity_threshold_theta;
+        double state_based = (double)((total / 4.0L) * 2.0L);
+        put_f64(std::tanh(state_based / c.tanh_temperature));
+    }
+    P.off_eff = (int)image.size(); // env_super.py:1058-1062
+    for (int d = 0; d <= S / 2; ++d) put_f64((1.0 - 4.0 * ((double)d / (double)S)) * c.bale_efficiency_factor);
+    P.off_acc = (int)image.size();
+    for (int r = 0; r < 3; ++r)
+        for (int m = 0; m < 4; ++m) put_f64(acc_rows[r][m]);
+    P.off_bonus = (int)image.size(); // env_super.py:1065-1069
+    for (int b = 0; b < 4; ++b) put_f64(peaks[b] - c.bale_efficiency_factor);
+    while (image.size() & 3u) image.push_back(0u); // 16-byte alignment of the per-stage records (read as float4)
+    P.off_pat = (int)image.size();
+    for (int k = 0; k < 3; ++k)
+        for (int w = 0; w < kPatStride; ++w) image.push_back(pat_rec[k][w]);
+    P.off_ptime = (int)image.size();
+    image.push_back((uint32_t)c.press_time[0]);
+    image.push_back((uint32_t)c.press_time[1]);
+    P.table_words = (int)image.size();
+    if (P.table_words > 16384) {
+        why = "container_capacity / bale_standard_size too large for the LDS-resident tables (64 KiB)";
+        return MSE_ERR_UNSUPPORTED_CONFIG;
+    }
+    return MSE_OK;
+}
+
+template <int KIND>
+static size_t lds_bytes_step(const mse_env *h)
+{
+    return (size_t)LdsLayout<KIND>::table_offset_step + (size_t)h->P.table_words * 4u;
+}
+template <int KIND>
+static size_t lds_bytes_rollout(const mse_env *h)
+{
+    return (size_t)LdsLayout<KIND>::table_offset_rollout + (size_t)h->P.table_words * 4u;
+}
+
 static inline dim3 grid_of(const mse_env *h) { return dim3((unsigned)(h->P.n_pad / kBlock)); }
 
 template <int KIND>
 static void launch_step(mse_env *h, hipStream_t s, const int32_t *action, const int32_t *sort_mode, uint32_t flags,
                         float *obs, float *rew, double *rew64, uint8_t *done, uint8_t *mask, float *tobs)
 {
-    const bool lit = h->cfg.literal_choice != 0;
+    const bool lit = h->literal;
+    const size_t lds = lds_bytes_step<KIND>(h);
 #define MSE_LAUNCH_STEP(NOISE, LIT)                                                                      \
-    hipLaunchKernelGGL((k_step<KIND, NOISE, LIT>), grid_of(h), dim3(kBlock), 0, s, h->P, h->planes, action, \
-                       sort_mode, flags, obs, rew, rew64, done, mask, tobs, h->err_count)
+    hipLaunchKernelGGL((k_step<KIND, NOISE, LIT>), grid_of(h), dim3(kBlock), lds, s, h->P, h->planes, h->tables, \
+                       action, sort_mode, flags, obs, rew, rew64, done, mask, tobs, h->err_count)
     if (h->noise_on) {
         if (lit) MSE_LAUNCH_STEP(true, true); else MSE_LAUNCH_STEP(true, false);
     } else {
@@ -421,10 +626,11 @@ template <int KIND>
 static void launch_rollout(mse_env *h, hipStream_t s, int k_steps, uint64_t policy_seed, const int32_t *sort_mode,
                            uint32_t flags, int32_t *actions, float *obs, float *rew, uint8_t *done, uint8_t *mask)
 {
-    const bool lit = h->cfg.literal_choice != 0;
+    const bool lit = h->literal;
+    const size_t lds = lds_bytes_rollout<KIND>(h);
 #define MSE_LAUNCH_ROLLOUT(NOISE, LIT)                                                                   \
-    hipLaunchKernelGGL((k_rollout<KIND, NOISE, LIT>), grid_of(h), dim3(kBlock), 0, s, h->P, h->planes, k_steps, \
-                       policy_seed, h->policy_t, sort_mode, flags, actions, obs, rew, done, mask)
+    hipLaunchKernelGGL((k_rollout<KIND, NOISE, LIT>), grid_of(h), dim3(kBlock), lds, s, h->P, h->planes, h->tables, \
+                       k_steps, policy_seed, h->policy_t, sort_mode, flags, actions, obs, rew, done, mask)
     if (h->noise_on) {
         if (lit) MSE_LAUNCH_ROLLOUT(true, true); else MSE_LAUNCH_ROLLOUT(true, false);
     } else {
@@ -544,36 +750,24 @@ int mse_create_indexed(mse_env **out, const mse_config *cfg, int64_t n_envs, int
     P.batch = cfg->input_batch_size;
     P.press_time[0] = cfg->press_time[0];
     P.press_time[1] = cfg->press_time[1];
-    for (int k = 0; k < 2; ++k) {
-        int sum = 0;
-        for (int m = 0; m < 4; ++m) {
-            // utils/input_generator.py:47: int(np.floor(ratio * batchsize))
-            P.pat[k][m] = (int)std::floor(cfg->pattern_ratio[k][m] * (double)cfg->input_batch_size);
-            sum += P.pat[k][m];
-        }
-        if (sum != cfg->input_batch_size) {
-            delete h;
-            return fail(MSE_ERR_UNSUPPORTED_CONFIG,
-                        "input_batch_size leaves a floor() remainder for a seasonal pattern: the generator's "
-                        "random remainder draws (utils/input_generator.py:50-55) are not on the restated path");
-        }
-    }
-    for (int m = 0; m < 4; ++m) {
-        P.base_acc[m] = cfg->baseline_accuracy[m];
-        P.thr[m] = cfg->quality_threshold[m];
-        P.thr_r2[m] = cfg->quality_threshold_r2[m];
-    }
+    for (int m = 0; m < 4; ++m) P.base_acc[m] = cfg->baseline_accuracy[m];
     P.boost = cfg->boost;
     P.noise = cfg->noise;
-    P.theta = cfg->purity_threshold_theta;
-    P.temperature = cfg->tanh_temperature;
     P.pen_cat = cfg->overflow_penalty_catastrophic;
     P.pen_sev = cfg->overflow_penalty_severe;
     P.pen_mild = cfg->overflow_penalty_mild;
-    P.bef = cfg->bale_efficiency_factor;
     P.max_state_reward = cfg->max_state_reward;
     P.overflow_pen = cfg->overflow_termination_penalty;
     P.rem_thr = cfg->bale_remainder_threshold;
+    std::vector<uint32_t> image;
+    std::string why;
+    int trc = build_tables(*cfg, P, image, why);
+    if (trc != MSE_OK) {
+        delete h;
+        return fail(trc, why);
+    }
+    // the byte-packed integer draw needs every prefix sum below 128; larger batches draw in literal fp64
+    h->literal = cfg->literal_choice != 0 || cfg->input_batch_size > 127;
 
     size_t bytes = (size_t)PL_COUNT * (size_t)P.n_pad * sizeof(uint4);
     hipError_t e1 = hipMalloc(reinterpret_cast<void **>(&h->planes), bytes);
@@ -587,6 +781,14 @@ int mse_create_indexed(mse_env **out, const mse_config *cfg, int64_t n_envs, int
         delete h;
         return fail(MSE_ERR_HIP, std::string("hipMalloc(err_count): ") + hipGetErrorString(e2));
     }
+    hipError_t e3 = hipMalloc(reinterpret_cast<void **>(&h->tables), image.size() * sizeof(uint32_t));
+    if (e3 != hipSuccess) {
+        (void)hipFree(h->planes);
+        (void)hipFree(h->err_count);
+        delete h;
+        return fail(MSE_ERR_HIP, std::string("hipMalloc(tables): ") + hipGetErrorString(e3));
+    }
+    MSE_HIP(hipMemcpy(h->tables, image.data(), image.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     MSE_HIP(hipMemset(h->planes, 0, bytes));
     MSE_HIP(hipMemset(h->err_count, 0, sizeof(unsigned long long)));
     *out = h;
@@ -598,6 +800,7 @@ int mse_destroy(mse_env *h)
     if (!h) return MSE_OK;
     (void)hipSetDevice(h->device);
     (void)hipFree(h->planes);
+    (void)hipFree(h->tables);
     (void)hipFree(h->err_count);
     delete h;
     return MSE_OK;
@@ -635,9 +838,9 @@ int mse_reset(mse_env *h, const uint64_t *seeds, const uint8_t *which, float *ob
         return fail(MSE_ERR_NOT_RESET, "the first mse_reset must seed every env (which_dev must be NULL)");
     hipStream_t s = static_cast<hipStream_t>(stream);
     switch (h->P.env_kind) {
-    case 1: hipLaunchKernelGGL(k_reset<1>, grid_of(h), dim3(kBlock), 0, s, h->P, h->planes, seeds, which, obs_out, mask_out); break;
-    case 2: hipLaunchKernelGGL(k_reset<2>, grid_of(h), dim3(kBlock), 0, s, h->P, h->planes, seeds, which, obs_out, mask_out); break;
-    default: hipLaunchKernelGGL(k_reset<3>, grid_of(h), dim3(kBlock), 0, s, h->P, h->planes, seeds, which, obs_out, mask_out); break;
+    case 1: hipLaunchKernelGGL(k_reset<1>, grid_of(h), dim3(kBlock), 0, s, h->P, h->planes, h->tables, seeds, which, obs_out, mask_out); break;
+    case 2: hipLaunchKernelGGL(k_reset<2>, grid_of(h), dim3(kBlock), 0, s, h->P, h->planes, h->tables, seeds, which, obs_out, mask_out); break;
+    default: hipLaunchKernelGGL(k_reset<3>, grid_of(h), dim3(kBlock), 0, s, h->P, h->planes, h->tables, seeds, which, obs_out, mask_out); break;
     }
     MSE_CHECK_LAUNCH();
     if (seeds) h->seeded = true;
@@ -728,7 +931,7 @@ int mse_set_state(mse_env *h, const int64_t *ints_in, const double *dbls_in, con
     if (!h) return fail(MSE_ERR_INVALID_ARGUMENT, "env is NULL");
     hipLaunchKernelGGL(k_set_state, grid_of(h), dim3(kBlock), 0, static_cast<hipStream_t>(stream), h->P, h->planes,
                        reinterpret_cast<const long long *>(ints_in), dbls_in,
-                       reinterpret_cast<const unsigned long long *>(rng_in));
+                       reinterpret_cast<const unsigned long long *>(rng_in), h->err_count);
     MSE_CHECK_LAUNCH();
     if (rng_in) h->seeded = true;
     return MSE_OK;

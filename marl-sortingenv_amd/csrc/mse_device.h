@@ -79,37 +79,64 @@ struct Pcg {
     uint64_t s_lo, s_hi, i_lo, i_hi;
 };
 
-// d = a * b + c on the 32x32+64 multiplier (v_mad_u64_u32; carry-out unused: callers never overflow
-// or work mod 2^64)
+// 32x32+64 multiply-add on v_mad_u64_u32 (quarter-rate op: the 128-bit LCG step is built from exactly
+// six of them plus four v_mul_lo_u32; hipcc's own expansion of the 64-bit C expression used 14).
+// The multiplier limb is a wave-uniform constant and goes on the scalar bus.
 __device__ __forceinline__ uint64_t mad64(uint32_t a, uint32_t b, uint64_t c)
 {
-    uint64_t d, carry;
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(d), "=s"(carry) : "v"(a), "v"(b), "v"(c));
+    uint64_t d;
+    asm("v_mad_u64_u32 %0, vcc, %1, %2, %3" : "=v"(d) : "v"(a), "s"(b), "v"(c) : "vcc");
+    return d;
+}
+__device__ __forceinline__ uint64_t mul64(uint32_t a, uint32_t b)
+{
+    uint64_t d;
+    asm("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "=v"(d) : "v"(a), "s"(b) : "vcc");
+    return d;
+}
+// the same with both factors per-lane values
+__device__ __forceinline__ uint64_t mul64_vv(uint32_t a, uint32_t b)
+{
+    uint64_t d;
+    asm("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "=v"(d) : "v"(a), "v"(b) : "vcc");
+    return d;
+}
+__device__ __forceinline__ uint32_t mul_lo_s(uint32_t a, uint32_t b)
+{
+    uint32_t d;
+    asm("v_mul_lo_u32 %0, %1, %2" : "=v"(d) : "v"(a), "s"(b));
     return d;
 }
 
-// state = state * 0x2360ED051FC65DA44385DF649FCCF645 + inc  (mod 2^128), on 32-bit limbs:
-// 6 v_mad_u64_u32 + 4 v_mul_lo_u32 (the minimum for a 128-bit constant multiplier) + carries
+// state = state * 0x2360ED051FC65DA44385DF649FCCF645 + inc  (mod 2^128), on 32-bit limbs
 __device__ __forceinline__ void pcg_advance(Pcg &g)
 {
     const uint32_t m0 = 0x9FCCF645u, m1 = 0x4385DF64u, m2 = 0x1FC65DA4u, m3 = 0x2360ED05u;
     const uint32_t s0 = (uint32_t)g.s_lo, s1 = (uint32_t)(g.s_lo >> 32);
     const uint32_t s2 = (uint32_t)g.s_hi, s3 = (uint32_t)(g.s_hi >> 32);
-    const uint64_t p0 = mad64(s0, m0, 0ull);
-    const uint64_t t1 = mad64(s0, m1, p0 >> 32);          // <= (2^32-1)^2 + 2^32-1 : no overflow
-    const uint64_t t2 = mad64(s1, m0, (uint64_t)(uint32_t)t1);
-    const uint64_t lo = (uint64_t)(uint32_t)p0 | (t2 << 32);
-    // limbs 2..3, everything mod 2^64
-    uint64_t hi = (t1 >> 32) + (t2 >> 32);
-    hi = mad64(s0, m2, hi);
-    hi = mad64(s1, m1, hi);
-    hi = mad64(s2, m0, hi);
-    const uint32_t top = s0 * m3 + s1 * m2 + s2 * m1 + s3 * m0;
-    hi = (uint64_t)(uint32_t)hi | ((uint64_t)((uint32_t)(hi >> 32) + top) << 32);
-    const uint64_t rlo = lo + g.i_lo;
-    hi += g.i_hi + (rlo < lo ? 1ull : 0ull);
-    g.s_lo = rlo;
-    g.s_hi = hi;
+    const uint64_t p0 = mul64(s0, m0);
+    const uint64_t A = mul64(s0, m1);
+    const uint64_t B = mul64(s1, m0);
+    // limb 1 = p0.hi + A.lo + B.lo; its two carries go into limb 2
+    uint32_t r1a, r1;
+    const uint32_t c1 = __builtin_uadd_overflow((uint32_t)(p0 >> 32), (uint32_t)A, &r1a) ? 1u : 0u;
+    const uint32_t c2 = __builtin_uadd_overflow(r1a, (uint32_t)B, &r1) ? 1u : 0u;
+    uint64_t h = (uint64_t)(uint32_t)(A >> 32) + (uint64_t)(uint32_t)(B >> 32) + (uint64_t)(c1 + c2);
+    h = mad64(s0, m2, h); // limbs 2..3, everything mod 2^64
+    h = mad64(s1, m1, h);
+    h = mad64(s2, m0, h);
+    const uint32_t h1 = (uint32_t)(h >> 32) + mul_lo_s(s0, m3) + mul_lo_s(s1, m2) + mul_lo_s(s2, m1) + mul_lo_s(s3, m0);
+    uint32_t o0, o1, o2, o3;
+    asm("v_add_co_u32 %0, vcc, %4, %8\n\t"
+        "v_addc_co_u32 %1, vcc, %5, %9, vcc\n\t"
+        "v_addc_co_u32 %2, vcc, %6, %10, vcc\n\t"
+        "v_addc_co_u32 %3, vcc, %7, %11, vcc"
+        : "=&v"(o0), "=&v"(o1), "=&v"(o2), "=&v"(o3)
+        : "v"((uint32_t)p0), "v"(r1), "v"((uint32_t)h), "v"(h1), "v"((uint32_t)g.i_lo), "v"((uint32_t)(g.i_lo >> 32)),
+          "v"((uint32_t)g.i_hi), "v"((uint32_t)(g.i_hi >> 32))
+        : "vcc");
+    g.s_lo = (uint64_t)o0 | ((uint64_t)o1 << 32);
+    g.s_hi = (uint64_t)o2 | ((uint64_t)o3 << 32);
 }
 
 __device__ __forceinline__ uint64_t pcg_output(const Pcg &g)
@@ -483,17 +510,20 @@ __device__ __forceinline__ int choice4_literal(uint32_t C, uint64_t r64)
 template <bool LITERAL>
 __device__ __forceinline__ void draw_units(Pcg &rng, uint32_t &C, int &rem)
 {
+#ifdef MSE_ABL_NODRAW
+    rem = 0;
+#endif
     while (rem > 0) {
-        pcg_advance(rng);
         const uint32_t T = C >> 24;
         if (T == 0u) { // env_super.py:557-559 (unreachable: the pool holds this station's own units)
             rem = 0;
             break;
         }
+        pcg_advance(rng);
         uint32_t flags; // bit 7 of byte k set iff bin k is passed over (c_k <= v)
         bool literal = LITERAL;
         if (!LITERAL) {
-            const uint64_t prod = mad64(pcg_output_hi32(rng), T, 0ull);
+            const uint64_t prod = mul64_vv(pcg_output_hi32(rng), T);
             const uint32_t f = (uint32_t)prod;
             const uint32_t v = (uint32_t)(prod >> 32);
             flags = (((v * 0x01010101u) | 0x80808080u) - C) & 0x00808080u;
@@ -582,6 +612,16 @@ __device__ __forceinline__ int sample_masked_press_action(Env &e, const Params &
     return select_kth_bit(bits, (int)(m >> 32));
 }
 
+// round(true/total, 2) in hundredths = rint(fl(fl(true/total) * 100)), the way numpy rounds
+// (env_super.py:754, 785-789).  The literal fp64 form is also the cheapest one here: at one wave per
+// SIMD a kernel pays ~5 cycles per instruction whatever it is, and the division sequence is ~14
+// instructions; an integer formulation (fp32 reciprocal, remainder fix-up, exact-tie table) was
+// measured 6 % slower end to end.
+__device__ __forceinline__ int purity_hundredths(int tru, int total)
+{
+    return (int)rint(((double)tru / (double)total) * 100.0);
+}
+
 // env_super.py:661-687 press_bale on the O(1) ledger summary {count, sum, last_size, last_q}
 __device__ __forceinline__ void press_bale(uint4 *cell, int balesize, double rem_thr, int n, int q100)
 {
@@ -659,7 +699,7 @@ __device__ __forceinline__ void press_action_rules(Env &e, const Params &P, cons
     e.lps = 1;
     e.lpa = total;
     int q = 0;
-    if (tru > 0) q = (int)rint(((double)tru / (double)total) * 100.0); // round(x, 2) in hundredths
+    if (tru > 0) q = purity_hundredths(tru, total); // round(x, 2)
     const int pt = press_time[p];
     if (p) {
         e.timer[1] = pt;
@@ -674,15 +714,16 @@ __device__ __forceinline__ void press_action_rules(Env &e, const Params &P, cons
     }
 }
 
-// env_super.py:771-791 get_container_purity per material, in hundredths:
-// round(true/total, 2) = rint((true/total)*100)/100; [101] marks an empty container (purity = threshold)
+// env_super.py:771-791 get_container_purity per material, in hundredths; [101] marks an empty
+// container (its purity is the quality threshold)
 __device__ __forceinline__ void container_purity_k(const Env &e, int k[4])
 {
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
-        int total = e.ct[m] + e.cf[m];
-        int v = (int)rint(((double)e.ct[m] / (double)(total > 0 ? total : 1)) * 100.0);
-        k[m] = total > 0 ? v : 101;
+        const int total = e.ct[m] + e.cf[m];
+        int v = 101;
+        if (total > 0) v = purity_hundredths(e.ct[m], total);
+        k[m] = v;
     }
 }
 

@@ -36,63 +36,77 @@ struct LdsLayout {
     static constexpr int table_offset_rollout = bale_offset + bale_bytes;
 };
 
-__device__ __forceinline__ void lds_barrier()
-{
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
-
 __device__ __forceinline__ void load_tables_to_lds(uint32_t *dst, const uint32_t *__restrict__ src, int words, int tid)
 {
     for (int w = tid; w < words; w += kBlock) dst[w] = src[w];
     __syncthreads();
 }
 
-// write this lane's rows, then the workgroup streams the tile out; gout_* point at the tile's first row
+// Each WAVE stages the 64 rows of its own lanes and streams them out itself: the rows of one wave are a
+// contiguous, 16-byte aligned run of the output (64 x 116 B for obs), and the LDS executes one wave's
+// instructions in order, so no workgroup barrier is needed (the first profile showed 36 % of wave time
+// parked at the per-step barriers).  gobs / gmask point at the WORKGROUP's first row.
 template <int KIND>
 __device__ __forceinline__ void stage_and_store(uint8_t *lds_base, const float *o, uint32_t mbits, float *gobs,
-                                                uint8_t *gmask, int n_valid, int tid)
+                                                uint8_t *gmask, int n_valid_block, int tid)
 {
     constexpr int D = Dims<KIND>::D, A = Dims<KIND>::A;
-    float *lobs = reinterpret_cast<float *>(lds_base);
-    uint8_t *lmask = lds_base + LdsLayout<KIND>::obs_bytes;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int n_valid = min(max(n_valid_block - wave * 64, 0), 64);
+    float *lobs = reinterpret_cast<float *>(lds_base) + wave * 64 * D;
+    uint8_t *lmask = lds_base + LdsLayout<KIND>::obs_bytes + wave * 64 * A;
     if (gobs != nullptr) {
 #pragma unroll
-        for (int j = 0; j < D; ++j) lobs[tid * D + j] = o[j];
+        for (int j = 0; j < D; ++j) lobs[lane * D + j] = o[j];
     }
     if (gmask != nullptr) {
-        // rows are A bytes (A even): two mask bytes per 16-bit LDS store
-        uint16_t *row = reinterpret_cast<uint16_t *>(lmask + tid * A);
+        if (A % 2 == 0) { // even row length: two mask bytes per 16-bit LDS store
+            uint16_t *row = reinterpret_cast<uint16_t *>(lmask + lane * A);
 #pragma unroll
-        for (int j = 0; j < A / 2; ++j)
-            row[j] = (uint16_t)(((mbits >> (2 * j)) & 1u) | (((mbits >> (2 * j + 1)) & 1u) << 8));
-        if (A & 1) lmask[tid * A + A - 1] = (uint8_t)((mbits >> (A - 1)) & 1u);
+            for (int j = 0; j < A / 2; ++j)
+                row[j] = (uint16_t)(((mbits >> (2 * j)) & 1u) | (((mbits >> (2 * j + 1)) & 1u) << 8));
+        } else {
+#pragma unroll
+            for (int j = 0; j < A; ++j) lmask[lane * A + j] = (uint8_t)((mbits >> j) & 1u);
+        }
     }
-    lds_barrier();
+    __builtin_amdgcn_wave_barrier();
     if (gobs != nullptr) {
+        float *g = gobs + wave * 64 * D;
         const int total = n_valid * D;
-        if ((reinterpret_cast<uintptr_t>(gobs) & 15u) == 0) {
+        if ((reinterpret_cast<uintptr_t>(g) & 15u) == 0) {
+            // all LDS reads first, then the 16-byte stores: one LDS latency per tile instead of one per piece
+            constexpr int NV = (64 * D / 4 + 63) / 64;
             const int nvec = total >> 2;
             const float4 *src = reinterpret_cast<const float4 *>(lobs);
-            float4 *dst = reinterpret_cast<float4 *>(gobs);
-            for (int v = tid; v < nvec; v += kBlock) dst[v] = src[v];
-            for (int q = (nvec << 2) + tid; q < total; q += kBlock) gobs[q] = lobs[q];
+            float4 *dst = reinterpret_cast<float4 *>(g);
+            float4 buf[NV];
+#pragma unroll
+            for (int j = 0; j < NV; ++j) buf[j] = src[lane + 64 * j]; // past the tile: still inside the LDS image, unused
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                const int v = lane + 64 * j;
+                if (v < nvec) dst[v] = buf[j];
+            }
+            for (int q = (nvec << 2) + lane; q < total; q += 64) g[q] = lobs[q];
         } else {
-            for (int q = tid; q < total; q += kBlock) gobs[q] = lobs[q];
+            for (int q = lane; q < total; q += 64) g[q] = lobs[q];
         }
     }
     if (gmask != nullptr) {
+        uint8_t *g = gmask + wave * 64 * A;
         const int total = n_valid * A;
-        if ((reinterpret_cast<uintptr_t>(gmask) & 15u) == 0) {
+        if ((reinterpret_cast<uintptr_t>(g) & 15u) == 0) {
             const int nvec = total >> 4;
             const uint4 *src = reinterpret_cast<const uint4 *>(lmask);
-            uint4 *dst = reinterpret_cast<uint4 *>(gmask);
-            for (int v = tid; v < nvec; v += kBlock) dst[v] = src[v];
-            for (int q = (nvec << 4) + tid; q < total; q += kBlock) gmask[q] = lmask[q];
+            uint4 *dst = reinterpret_cast<uint4 *>(g);
+            for (int v = lane; v < nvec; v += 64) dst[v] = src[v];
+            for (int q = (nvec << 4) + lane; q < total; q += 64) g[q] = lmask[q];
         } else {
-            for (int q = tid; q < total; q += kBlock) gmask[q] = lmask[q];
+            for (int q = lane; q < total; q += 64) g[q] = lmask[q];
         }
     }
-    lds_barrier(); // the tile may be overwritten after this
+    __builtin_amdgcn_wave_barrier(); // the tile is rewritten by this wave only, after its own reads
 }
 
 // auto-reset of a finished episode inside the step (reset(seed=None) semantics: streams continue)
@@ -216,10 +230,15 @@ __global__ __launch_bounds__(kBlock) void k_rollout(Params P, uint4 *__restrict_
             uint32_t cnt = (uint32_t)__popc(cur);
             uint32_t rr = policy_u32(policy_seed, (uint64_t)(P.index_offset + i), policy_t0 + (uint64_t)s);
             int a = select_kth_bit(cur, (int)(((uint64_t)rr * cnt) >> 32));
+#ifdef MSE_ABL_NOPOLICY
+            a = (int)(s & 1) * 11;
+#endif
             int k[4];
             StepResult r = env_step<KIND, NOISE, LITERAL>(e, P, tb, a, sm, flags, bales, k);
             if (r.done) auto_reset_env(e, P, bales, k);
+#ifndef MSE_ABL_NOOBS
             env_obs<KIND>(e, P, tb, k, o);
+#endif
             mbits = action_mask_bits<KIND>(e, P);
             if (actions_out != nullptr) actions_out[(long long)s * P.n + i] = a;
             if (reward_out != nullptr) reward_out[(long long)s * P.n + i] = (float)r.reward;
@@ -537,7 +556,6 @@ static int build_tables(const mse_config &c, Params &P, std::vector<uint32_t> &i
         acc_rows[2][m] = lo_c;
     }
     const double peaks[4] = {0.0, 1.0 / 3.0, 2.0 / 3.0, 1.0}; // env_super.py:1065
-
     auto put_f32 = [&](float v) {
         uint32_t u;
         std::memcpy(&u, &v, 4);

@@ -1,0 +1,132 @@
+"""GPU: the host-side mirrors of the reference interface (single-env Gymnasium views, the SB3
+VecEnv-protocol adapter) and the C-ABI error behaviour."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from oracle.oracle import OracleEnv
+from tests import replay
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name,cls", [("mono_n5_masked_s0_s3", "Env_3_Monolith"),
+                                      ("press_n0_masked_s1_s42", "Env_2_Pressing"),
+                                      ("sort_n5_masked_s0_s3", "Env_1_Sorting")])
+def test_single_env_gymnasium_surface_matches_golden(name, cls):
+    """reset(seed) -> (obs, {}), step(a) -> (obs, float, bool, False, info), action_masks() -> bool[A],
+    exactly like the reference's classes, against the reference's recorded outputs."""
+    import marl_sortingenv_amd as M
+
+    meta, z = replay.load(os.path.join(replay.GOLDEN_DIR, name + ".npz"))
+    env = getattr(M, cls)(max_steps=meta["max_steps"], seed=meta["ctor_seed"], noise_sorting=meta["noise_sorting"],
+                          balesize=meta["balesize"])
+    assert env.name == meta["kind"]
+    assert env.observation_space.shape == (z["obs"].shape[1],) and env.action_space.n == z["mask"].shape[1]
+    for t in range(min(len(z["op"]), 260)):
+        if z["op"][t] == 1:
+            obs, info = env.reset(seed=int(z["arg"][t]))
+            assert info == {}
+        else:
+            a = int(z["arg"][t])
+            if meta["kind"] == "press":
+                class Agent:  # the reference's hook for the sorting decision (env_2_press.py:101-104)
+                    def predict(self, o, deterministic=True, mode=int(z["sort_mode"][t])):
+                        return mode, None
+                env.set_agents(sort_agent=Agent())
+            obs, rew, term, trunc, info = env.step(a)
+            assert isinstance(rew, float) and isinstance(term, bool) and trunc is False
+            assert info["action"] == a
+            assert abs(rew - float(z["reward"][t])) <= 1e-6 and term == bool(z["terminated"][t])
+        assert obs.dtype == np.float32 and np.array_equal(obs.view(np.uint32), z["obs"][t].view(np.uint32)), t
+        m = env.action_masks()
+        assert m.dtype == bool and np.array_equal(m, z["mask"][t].astype(bool)), t
+        assert env.observation_space.contains(obs)
+    env.close()
+
+
+def test_vec_env_adapter_protocol():
+    """SB3 VecEnv protocol: numpy in/out, auto-reset with infos[i]['terminal_observation'],
+    env_method('action_masks')."""
+    import marl_sortingenv_amd as M
+
+    n, T = 130, 12
+    venv = M.SortingVecEnv(kind="mono", num_envs=n, base_seed=9, max_steps=T, noise_sorting=0.05)
+    oracles = [OracleEnv(kind="mono", max_steps=T, seed=9 + i, noise_sorting=0.05) for i in range(n)]
+    obs = venv.reset()
+    assert obs.shape == (n, 29) and obs.dtype == np.float32
+    for i, o in enumerate(oracles):
+        assert np.array_equal(obs[i], o.reset(9 + i))
+    rng = np.random.default_rng(0)
+    for t in range(2 * T + 3):
+        masks = np.stack(venv.env_method("action_masks"))
+        assert masks.shape == (n, 22) and masks.dtype == bool
+        act = np.array([rng.choice(np.flatnonzero(m)) for m in masks])
+        obs, rew, done, infos = venv.step(act)
+        assert obs.dtype == np.float32 and rew.dtype == np.float32 and done.dtype == bool and len(infos) == n
+        for i, o in enumerate(oracles):
+            eo, er, et = o.step(int(act[i]))
+            assert abs(er - float(rew[i])) <= 1e-6 and bool(done[i]) == et
+            if et:
+                assert np.array_equal(infos[i]["terminal_observation"].view(np.uint32), eo.view(np.uint32))
+                eo = o.reset(None)
+            else:
+                assert "terminal_observation" not in infos[i]
+            assert np.array_equal(obs[i].view(np.uint32), eo.view(np.uint32))
+    assert venv.get_attr("name") == ["mono"] * n and venv.env_is_wrapped(object) == [False] * n
+    venv.close()
+
+
+def test_env2_rule_based_sorting_fallback():
+    """Env_2 without a sort agent: sorting_rules() (env_super.py:469-482) evaluated on the device."""
+    import torch
+    import marl_sortingenv_amd as M
+
+    n = 70
+    env = M.BatchedSortingEnv(kind="press", num_envs=n, base_seed=3, max_steps=60, noise_sorting=0.0, auto_reset=False)
+    oracles = [OracleEnv(kind="press", max_steps=60, seed=3 + i, noise_sorting=0.0) for i in range(n)]
+    for i, o in enumerate(oracles):
+        o.reset(3 + i)
+    for t in range(55):
+        act = env.sample_actions(policy_seed=t)
+        obs, rew, done, mask = env.step(act, sort_mode=None, want_reward64=True)
+        a = act.cpu().numpy()
+        for i, o in enumerate(oracles):
+            eo, er, et = o.step(int(a[i]), -1)
+            assert np.array_equal(obs[i].cpu().numpy().view(np.uint32), eo.view(np.uint32)), (t, i)
+            assert abs(er - float(env.reward64[i])) <= 1e-6
+
+
+def test_c_abi_error_behaviour():
+    import torch
+    import marl_sortingenv_amd as M
+    from marl_sortingenv_amd._lib import MseError
+
+    env = M.BatchedSortingEnv(kind="mono", num_envs=8, reset_now=False)
+    act = torch.zeros(8, dtype=torch.int32, device="cuda")
+    with pytest.raises(MseError) as ei:
+        env.step(act)                      # step before the first seeded reset
+    assert ei.value.status == -5
+    with pytest.raises(MseError):
+        env.reset(seeds=None)              # an unseeded first reset cannot work either
+    env.reset(seeds=torch.arange(8))
+    env.step(act)
+    # out-of-range actions are counted and treated as action 0, never a fault
+    bad = torch.tensor([0, 22, -1, 5, 99, 0, 0, 0], dtype=torch.int32, device="cuda")
+    env.step(bad)
+    assert env.error_count() == 3
+    # a misaligned obs buffer is refused (the 16-byte store path needs it)
+    L = M.load_library()
+    raw = torch.zeros(8 * 29 + 4, dtype=torch.float32, device="cuda")
+    rc = L.mse_step(env._h, C.c_void_p(act.data_ptr()), None, 0, C.c_void_p(raw.data_ptr() + 4), None, None,
+                    C.c_void_p(env.done.data_ptr()), None, None, None)
+    assert rc == -6 and b"aligned" in L.mse_last_error()
+    with pytest.raises(MseError):
+        env.rollout(0)
+    # configurations outside the restated path are refused loudly at create time
+    cfg = M.SortingEnvConfig(input_batch_size=90)  # floor() remainder -> generator RNG draws
+    with pytest.raises(MseError) as ei:
+        M.BatchedSortingEnv(kind="mono", num_envs=4, config=cfg)
+    assert ei.value.status == -2

@@ -108,32 +108,30 @@ __device__ __forceinline__ uint32_t mul_lo_s(uint32_t a, uint32_t b)
     return d;
 }
 
-// state = state * 0x2360ED051FC65DA44385DF649FCCF645 + inc  (mod 2^128), on 32-bit limbs
+// state = state * 0x2360ED051FC65DA44385DF649FCCF645 + inc  (mod 2^128), on 32-bit limbs.
+// Carries ride in the 64-bit accumulator of v_mad_u64_u32: limb sums that can exceed 32 bits are
+// fed back as the (zero-extended) addend of the next multiply-add.
 __device__ __forceinline__ void pcg_advance(Pcg &g)
 {
     const uint32_t m0 = 0x9FCCF645u, m1 = 0x4385DF64u, m2 = 0x1FC65DA4u, m3 = 0x2360ED05u;
     const uint32_t s0 = (uint32_t)g.s_lo, s1 = (uint32_t)(g.s_lo >> 32);
     const uint32_t s2 = (uint32_t)g.s_hi, s3 = (uint32_t)(g.s_hi >> 32);
-    const uint64_t p0 = mul64(s0, m0);
-    const uint64_t A = mul64(s0, m1);
-    const uint64_t B = mul64(s1, m0);
-    // limb 1 = p0.hi + A.lo + B.lo; its two carries go into limb 2
-    uint32_t r1a, r1;
-    const uint32_t c1 = __builtin_uadd_overflow((uint32_t)(p0 >> 32), (uint32_t)A, &r1a) ? 1u : 0u;
-    const uint32_t c2 = __builtin_uadd_overflow(r1a, (uint32_t)B, &r1) ? 1u : 0u;
-    uint64_t h = (uint64_t)(uint32_t)(A >> 32) + (uint64_t)(uint32_t)(B >> 32) + (uint64_t)(c1 + c2);
-    h = mad64(s0, m2, h); // limbs 2..3, everything mod 2^64
-    h = mad64(s1, m1, h);
-    h = mad64(s2, m0, h);
-    const uint32_t h1 = (uint32_t)(h >> 32) + mul_lo_s(s0, m3) + mul_lo_s(s1, m2) + mul_lo_s(s2, m1) + mul_lo_s(s3, m0);
+    const uint64_t p0 = mul64(s0, m0);                            // limb 0 | carry
+    const uint64_t x = mad64(s0, m1, (uint64_t)(uint32_t)(p0 >> 32)); // <= (2^32-1)^2 + 2^32-1: no overflow
+    const uint64_t y = mad64(s1, m0, (uint64_t)(uint32_t)x);          // limb 1 | carry
+    uint64_t z = mad64(s0, m2, (uint64_t)(uint32_t)(x >> 32));        // limbs 2..3, everything mod 2^64
+    z = mad64(s1, m1, z);
+    z = mad64(s2, m0, z);
+    z += (uint64_t)(uint32_t)(y >> 32);
+    const uint32_t h1 = (uint32_t)(z >> 32) + mul_lo_s(s0, m3) + mul_lo_s(s1, m2) + mul_lo_s(s2, m1) + mul_lo_s(s3, m0);
     uint32_t o0, o1, o2, o3;
     asm("v_add_co_u32 %0, vcc, %4, %8\n\t"
         "v_addc_co_u32 %1, vcc, %5, %9, vcc\n\t"
         "v_addc_co_u32 %2, vcc, %6, %10, vcc\n\t"
         "v_addc_co_u32 %3, vcc, %7, %11, vcc"
         : "=&v"(o0), "=&v"(o1), "=&v"(o2), "=&v"(o3)
-        : "v"((uint32_t)p0), "v"(r1), "v"((uint32_t)h), "v"(h1), "v"((uint32_t)g.i_lo), "v"((uint32_t)(g.i_lo >> 32)),
-          "v"((uint32_t)g.i_hi), "v"((uint32_t)(g.i_hi >> 32))
+        : "v"((uint32_t)p0), "v"((uint32_t)y), "v"((uint32_t)z), "v"(h1), "v"((uint32_t)g.i_lo),
+          "v"((uint32_t)(g.i_lo >> 32)), "v"((uint32_t)g.i_hi), "v"((uint32_t)(g.i_hi >> 32))
         : "vcc");
     g.s_lo = (uint64_t)o0 | ((uint64_t)o1 << 32);
     g.s_hi = (uint64_t)o2 | ((uint64_t)o3 << 32);
@@ -513,12 +511,10 @@ __device__ __forceinline__ void draw_units(Pcg &rng, uint32_t &C, int &rem)
 #ifdef MSE_ABL_NODRAW
     rem = 0;
 #endif
+    // env_super.py:557-559 breaks out when the pool is empty.  That cannot happen: a station starts its
+    // draws with its own false units in the pool (T >= rem) and every draw lowers both T and rem by one.
     while (rem > 0) {
         const uint32_t T = C >> 24;
-        if (T == 0u) { // env_super.py:557-559 (unreachable: the pool holds this station's own units)
-            rem = 0;
-            break;
-        }
         pcg_advance(rng);
         uint32_t flags; // bit 7 of byte k set iff bin k is passed over (c_k <= v)
         bool literal = LITERAL;
@@ -526,7 +522,7 @@ __device__ __forceinline__ void draw_units(Pcg &rng, uint32_t &C, int &rem)
             const uint64_t prod = mul64_vv(pcg_output_hi32(rng), T);
             const uint32_t f = (uint32_t)prod;
             const uint32_t v = (uint32_t)(prod >> 32);
-            flags = (((v * 0x01010101u) | 0x80808080u) - C) & 0x00808080u;
+            flags = ((__umul24(v, 0x010101u) | 0x00808080u) - C) & 0x00808080u; // bytes 0..2 only; v < 128
             literal = (f + 0x200u) < 0x210u; // f < 16 or f >= 2^32 - 512
         }
         if (literal) {

@@ -55,6 +55,10 @@ constexpr int kPdiffStride = 102; // purity hundredths 0..100, [101] = empty con
 //   [4..7] belt proportions f32   [8..11] sorting[m]/stage_capacity f32
 constexpr int kPatStride = 12;
 
+// fp64 constants kept in the LDS table image (Tables::cst)
+enum Cst : int { CST_PEN_CAT = 0, CST_PEN_SEV, CST_PEN_MILD, CST_MAX_STATE, CST_OVERFLOW_PEN, CST_REM_THR, CST_BOOST,
+                 CST_NOISE, CST_BASE_ACC0, CST_BASE_ACC1, CST_BASE_ACC2, CST_BASE_ACC3, CST_COUNT };
+
 struct Params {
     long long n;            // envs in this handle
     long long n_pad;        // plane stride (multiple of kBlock)
@@ -62,14 +66,15 @@ struct Params {
     int env_kind, max_steps, auto_reset, track_bales;
     int balesize, capacity, stage_capacity, batch;
     int press_time[2];
+    int press_time0, press_time1; // the same as two scalars: selected per lane with v_cndmask, never indexed
+    float inv_balesize;           // 1.0f / bale_standard_size (quotient estimate, fixed up exactly)
+    double max_state_reward;      // used every step: stays a kernel argument (SGPR pair)
     // stage vectors are one of three words: id 0 = empty (after reset), 1 / 2 = seasonal pattern
     uint32_t pat_word[3];   // packed u8x4 counts A..D (load/store conversion only; the step reads the LDS copy)
     int thr_sev, thr_mild;  // levels above these have fill_ratio > 0.95 / > 0.90 (literal fp64 scan on the host)
     int k_thr[4];           // hundredths of python round(quality_threshold, 2): purity of an empty container
-    double base_acc[4], boost, noise;
-    double pen_cat, pen_sev, pen_mild, max_state_reward, overflow_pen, rem_thr;
     // offsets (in 4-byte words) into the table image; see build_tables
-    int off_lvl, off_pdiff, off_timer0, off_timer1, off_tanh, off_eff, off_pat, off_acc, off_bonus, off_ptime, table_words;
+    int off_lvl, off_pdiff, off_timer0, off_timer1, off_tanh, off_eff, off_pat, off_acc, off_bonus, off_ptime, off_cst, table_words;
 };
 
 // ------------------------------------------------------------------------------------------
@@ -242,10 +247,20 @@ __device__ __forceinline__ uint64_t mix64(uint64_t z)
     return z ^ (z >> 31);
 }
 
+// counter-based random policy word for (policy seed, global env index, step counter): murmur3's 32-bit
+// finaliser over an odd-constant combination of the three (10 instructions; a 64-bit splitmix cost 25)
 __device__ __forceinline__ uint32_t policy_u32(uint64_t seed, uint64_t env_index, uint64_t t)
 {
-    uint64_t x = seed ^ (env_index * 0x9E3779B97F4A7C15ull) ^ (t * 0xD1B54A32D192ED03ull);
-    return (uint32_t)(mix64(x) >> 32);
+    const uint32_t s32 = (uint32_t)seed ^ ((uint32_t)(seed >> 32) * 0x85EBCA6Bu);
+    const uint32_t g32 = (uint32_t)env_index ^ ((uint32_t)(env_index >> 32) * 0xC2B2AE35u);
+    const uint32_t t32 = (uint32_t)t ^ ((uint32_t)(t >> 32) * 0x27D4EB2Fu);
+    uint32_t h = s32 + g32 * 0x9E3779B1u + t32 * 0x85EBCA77u;
+    h ^= h >> 16;
+    h *= 0x85EBCA6Bu;
+    h ^= h >> 13;
+    h *= 0xC2B2AE35u;
+    h ^= h >> 16;
+    return h;
 }
 
 // index of the k-th (0-based) set bit of `bits`
@@ -449,7 +464,7 @@ __device__ __forceinline__ void update_environment(Env &e)
 
 // env_super.py:484-509 set_multisensor_mode + update_accuracy; acc_sorter gets the OLD accuracy_belt
 template <bool NOISE>
-__device__ __forceinline__ void update_accuracy(Env &e, const Params &P, const double *acc_table, int mode,
+__device__ __forceinline__ void update_accuracy(Env &e, const double *cst, const double *acc_table, int mode,
                                                 double acc_sorter[4])
 {
 #pragma unroll
@@ -459,13 +474,14 @@ __device__ __forceinline__ void update_accuracy(Env &e, const Params &P, const d
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
             bool boosted = (m == 0 || m == 2) ? (mode == 0) : (mode == 1);
-            double a = P.base_acc[m];
-            if (boosted) a = a + P.boost;
+            double a = cst[CST_BASE_ACC0 + m];
+            if (boosted) a = a + cst[CST_BOOST];
             // Generator.uniform(-n, n): low + (high-low)*random(), separately rounded
-            double range = P.noise - (-P.noise);
+            const double noise = cst[CST_NOISE];
+            double range = noise - (-noise);
             double u = u64_to_unit_double(pcg_next64(e.noise));
             double scaled = range * u;
-            double v = a + ((-P.noise) + scaled);
+            double v = a + ((-noise) + scaled);
             e.acc[m] = v < 0.0 ? 0.0 : (v > 1.0 ? 1.0 : v);
         }
     } else {
@@ -661,7 +677,7 @@ struct BaleRef {
 };
 
 // env_super.py:626-640 press_action_rules = check_press_status (:642-659) then use_press (:722-769)
-__device__ __forceinline__ void press_action_rules(Env &e, const Params &P, const int *press_time, int press_action,
+__device__ __forceinline__ void press_action_rules(Env &e, const Params &P, const double *cst, int press_action,
                                                    const BaleRef &bales)
 {
 #pragma unroll
@@ -669,7 +685,7 @@ __device__ __forceinline__ void press_action_rules(Env &e, const Params &P, cons
         if (e.timer[p] > 0) {
             e.timer[p] -= 1;
             if (e.timer[p] == 0) {
-                if (P.track_bales) press_bale(bales.cell(e.pmat[p]), P.balesize, P.rem_thr, e.pn[p], e.q100[p]);
+                if (P.track_bales) press_bale(bales.cell(e.pmat[p]), P.balesize, cst[CST_REM_THR], e.pn[p], e.q100[p]);
                 e.pmat[p] = 0xFF;
                 e.pn[p] = 0;
                 e.q100[p] = 0;
@@ -696,7 +712,8 @@ __device__ __forceinline__ void press_action_rules(Env &e, const Params &P, cons
     e.lpa = total;
     int q = 0;
     if (tru > 0) q = purity_hundredths(tru, total); // round(x, 2)
-    const int pt = press_time[p];
+    const int pt0 = P.press_time0, pt1 = P.press_time1;
+    const int pt = p ? pt1 : pt0;
     if (p) {
         e.timer[1] = pt;
         e.pmat[1] = mat;
@@ -737,6 +754,9 @@ struct Tables {
     const double *acc;    // [3][4]       clip(baseline + boost by mode 0 | 1 | none) env_super.py:499-509
     const double *bonus;  // [4]          target_peaks[min(num_bales,3)] - bale_efficiency_factor  :1065-1069
     const int *press_time; // [2]
+    // rarely used fp64 constants live here too: as kernel arguments they were re-fetched with s_load inside
+    // the step loop (SGPR pressure), each fetch a scalar-cache round trip
+    const double *cst;     // [CST_COUNT], see enum Cst
 };
 
 __device__ __forceinline__ Tables tables_at(const uint32_t *base, const Params &P)
@@ -752,6 +772,7 @@ __device__ __forceinline__ Tables tables_at(const uint32_t *base, const Params &
     t.acc = reinterpret_cast<const double *>(base + P.off_acc);
     t.bonus = reinterpret_cast<const double *>(base + P.off_bonus);
     t.press_time = reinterpret_cast<const int *>(base + P.off_ptime);
+    t.cst = reinterpret_cast<const double *>(base + P.off_cst);
     return t;
 }
 
@@ -782,12 +803,12 @@ __device__ __forceinline__ double press_reward(Env &e, const Params &P, const Ta
         any_sev |= sev;
         any_mild |= mild;
     }
-    if (any_cat) return P.pen_cat;
+    if (any_cat) return tb.cst[CST_PEN_CAT];
     double max_pen = 0.0;
-    if (any_sev) max_pen = fmin(max_pen, P.pen_sev);
-    if (any_mild) max_pen = fmin(max_pen, P.pen_mild);
+    if (any_sev) max_pen = fmin(max_pen, tb.cst[CST_PEN_SEV]);
+    if (any_mild) max_pen = fmin(max_pen, tb.cst[CST_PEN_MILD]);
     if (max_pen < 0.0) return max_pen;
-    double state_reward = ((double)total_level / (double)(5 * P.capacity)) * P.max_state_reward;
+    double state_reward = ((double)total_level / (double)(5 * P.capacity)) * tb.cst[CST_MAX_STATE];
     double action_reward = 0.0;
     if (e.lps) {
         const int S = P.balesize;
@@ -876,13 +897,13 @@ __device__ __forceinline__ int unseeded_gen2(const Env &e)
 }
 
 // env_super.py:365-420 reset (state part; streams and episode count are handled by the caller)
-__device__ __forceinline__ void reset_episode_state(Env &e, const Params &P)
+__device__ __forceinline__ void reset_episode_state(Env &e, const double *cst)
 {
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
         e.ct[m] = 0;
         e.cf[m] = 0;
-        e.acc[m] = P.base_acc[m];
+        e.acc[m] = cst[CST_BASE_ACC0 + m];
     }
     e.st_in = e.st_belt = e.st_sort = 0;
     e.ce = 0;
@@ -909,11 +930,30 @@ struct StepResult {
     int done;
 };
 
+// amount // S and amount % S for 0 <= amount < 2^24 without a division: fp32 estimate, exact fix-up
+__device__ __forceinline__ void divmod_small(int amount, int S, float inv_S, int &q, int &r)
+{
+    q = (int)((float)amount * inv_S);
+    r = amount - q * S;
+    if (r < 0) {
+        q -= 1;
+        r += S;
+    } else if (r >= S) {
+        q += 1;
+        r -= S;
+    }
+}
+
 // One env transition: env_1_sort.py:97-154 / env_2_press.py:88-165 / env_monolith.py:109-284.
-// `k` returns the post-step container purities (hundredths) for the observation.
+// Returns the reward and done flag, the post-step purities k[] (hundredths) and the post-step
+// observation o[] (before any auto-reset).
+//
+// Table reads are issued in two batches and consumed behind fp64 divisions: at one wave per SIMD an
+// LDS read that is waited for right after its issue costs the full ~150-cycle round trip (the v3
+// profile had ~25 such waits per step, 38 % of the wave's cycles).
 template <int KIND, bool NOISE, bool LITERAL>
 __device__ __forceinline__ StepResult env_step(Env &e, const Params &P, const Tables &tb, int action, int sort_mode_in,
-                                               uint32_t flags, const BaleRef &bales, int k[4])
+                                               uint32_t flags, const BaleRef &bales, int k[4], float *o)
 {
     const bool unmasked = (flags & 1u) != 0;
     const bool check_overflow = (flags & 2u) != 0;
@@ -921,6 +961,7 @@ __device__ __forceinline__ StepResult env_step(Env &e, const Params &P, const Ta
     // input_action_rules draws rng_input.integers(60,81) and discards it (env_super.py:911-922, :433);
     // that stream is never observed, so it is not carried.
     update_environment(e);
+    const uint32_t sorting_word = tb.pat[e.st_sort * kPatStride]; // issued first, needed at the first station
 
     int sort_mode, press_action = 0;
     bool run_press_rules = true;
@@ -939,8 +980,10 @@ __device__ __forceinline__ StepResult env_step(Env &e, const Params &P, const Ta
     }
 
     double acc_sorter[4];
-    update_accuracy<NOISE>(e, P, tb.acc, sort_mode, acc_sorter);
-    sort_material<LITERAL>(e, tb.pat[e.st_sort * kPatStride], acc_sorter);
+    update_accuracy<NOISE>(e, tb.cst, tb.acc, sort_mode, acc_sorter);
+#ifndef MSE_ABL_NOSORT
+    sort_material<LITERAL>(e, sorting_word, acc_sorter);
+#endif
 
     if (KIND == 1) {
         press_action = sample_masked_press_action(e, P); // env_1_sort.py:125-126 (mask before the tick)
@@ -948,31 +991,142 @@ __device__ __forceinline__ StepResult env_step(Env &e, const Params &P, const Ta
         // env_2_press.py:125-138: validated against post-sort levels; the timers still tick
         if (unmasked && !press_action_valid(e, P, press_action)) press_action = 0;
     }
-    if (run_press_rules) press_action_rules(e, P, tb.press_time, press_action, bales);
+#ifndef MSE_ABL_NOPRESS
+    if (run_press_rules) press_action_rules(e, P, tb.cst, press_action, bales);
+#endif
 
-    StepResult r;
-    container_purity_k(e, k);
-    if (check_overflow) { // env_super.py:900-905 + the variants' early return
-        bool over = false;
+    // ---- batch A: everything that needs only the post-press integer state -----------------------
+    int lvl[5];
 #pragma unroll
-        for (int m = 0; m < 5; ++m) over = over || (level_of(e, m) > P.capacity);
-        if (over) {
-            e.step += 1;
-            r.reward = P.overflow_pen;
-            r.done = 1;
-            return r;
+    for (int m = 0; m < 5; ++m) lvl[m] = level_of(e, m);
+    float lvl_f[5], timer_f[2], occ_f = 0.0f;
+    float4 prop = make_float4(0.f, 0.f, 0.f, 0.f), frac = prop;
+    if (KIND != 1) { // get_press_obs pieces (env_super.py:327-359)
+#pragma unroll
+        for (int m = 0; m < 5; ++m) lvl_f[m] = tb.lvl[lvl[m] < P.capacity ? lvl[m] : P.capacity];
+        timer_f[0] = tb.timer0[e.timer[0]];
+        timer_f[1] = tb.timer1[e.timer[1]];
+        frac = *reinterpret_cast<const float4 *>(tb.pat + e.st_sort * kPatStride + 8);
+    }
+    if (KIND != 2) { // get_sort_obs pieces (env_super.py:306-325)
+        const uint32_t *rec = tb.pat + e.st_belt * kPatStride;
+        occ_f = __uint_as_float(rec[1]);
+        prop = *reinterpret_cast<const float4 *>(rec + 4);
+    }
+    // action part of calculate_press_reward (env_super.py:1052-1075), branch-free: without a started
+    // press the amount is 0 and the looked-up value is discarded
+    double eff_v = 0.0, bonus_v = 0.0;
+    if (KIND != 1) {
+        const int amount = e.lps ? e.lpa : 0;
+        int nb, rem;
+        divmod_small(amount, P.balesize, P.inv_balesize, nb, rem);
+        const int dist = rem < P.balesize - rem ? rem : P.balesize - rem;
+        eff_v = tb.eff[dist];
+        bonus_v = tb.bonus[nb > 3 ? 3 : nb];
+    }
+
+    // ---- purity: four fp64 divisions (they also cover batch A's LDS latency) ---------------------
+    StepResult r;
+#ifdef MSE_ABL_NOREWARD
+    k[0] = k[1] = k[2] = k[3] = 101;
+#else
+    container_purity_k(e, k);
+#endif
+
+    // ---- batch B: reads keyed by the purities ---------------------------------------------------
+    float pdiff_f[4] = {0.f, 0.f, 0.f, 0.f};
+    double tanh_v = 0.0;
+    if (KIND != 2) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) pdiff_f[m] = tb.pdiff[m * kPdiffStride + k[m]];
+        int s = 0;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) s += (k[m] == 101) ? P.k_thr[m] : k[m];
+        tanh_v = tb.tanh_s[s]; // calculate_sorting_reward (env_super.py:963-1003), see Tables::tanh_s
+    }
+
+    // ---- calculate_press_reward (env_super.py:1006-1080); its division covers batch B ------------
+    double rp = 0.0;
+    bool over = false;
+    if (KIND != 1) {
+        bool any_cat = false, any_sev = false, any_mild = false;
+        int total_level = 0;
+#pragma unroll
+        for (int m = 0; m < 5; ++m) {
+            total_level += lvl[m];
+            const bool cat = lvl[m] > P.capacity;                  // fill_ratio > 1.0
+            const bool sev = !cat && lvl[m] > P.thr_sev;           // elif fill_ratio > 0.95
+            const bool mild = !cat && !sev && lvl[m] > P.thr_mild; // elif fill_ratio > 0.90
+            any_cat |= cat;
+            any_sev |= sev;
+            any_mild |= mild;
+        }
+        over = any_cat;
+        const double state_reward = ((double)total_level / (double)(5 * P.capacity)) * P.max_state_reward;
+        // penalty returns (env_super.py:1022-1030) happen BEFORE the flags are cleared: _last_press_* stay latched
+        bool penalised = any_cat;
+        double penalty = 0.0;
+        if (any_cat || any_sev || any_mild) { // rare: the constants are fetched only here
+            double max_pen = 0.0;
+            if (any_sev) max_pen = fmin(max_pen, tb.cst[CST_PEN_SEV]);
+            if (any_mild) max_pen = fmin(max_pen, tb.cst[CST_PEN_MILD]);
+            penalty = any_cat ? tb.cst[CST_PEN_CAT] : max_pen;
+            penalised = any_cat || max_pen < 0.0;
+        }
+        if (penalised) {
+            rp = penalty;
+        } else {
+            const double ar = e.lps ? eff_v + bonus_v : 0.0;
+            const double v = state_reward + ar;
+            rp = v < -1.0 ? -1.0 : (v > 1.0 ? 1.0 : v);
+            e.lps = 0;
+            e.lpa = 0;
         }
     }
     if (KIND == 1) {
-        r.reward = sorting_reward(P, tb, k);
-    } else if (KIND == 2) {
-        r.reward = press_reward(e, P, tb);
-    } else {
-        double rs = sorting_reward(P, tb, k);
-        double rp = press_reward(e, P, tb);
-        r.reward = rs + rp;
+#pragma unroll
+        for (int m = 0; m < 5; ++m) over = over || (lvl[m] > P.capacity);
     }
+#ifdef MSE_ABL_NOREWARD
+    rp = 0.0;
+    tanh_v = 0.0;
+#endif
+
+    // ---- observation (env_super.py:306-359) ------------------------------------------------------
+    if (KIND != 2) {
+        o[0] = occ_f;
+        o[1] = prop.x;
+        o[2] = prop.y;
+        o[3] = prop.z;
+        o[4] = prop.w;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) o[5 + m] = clip_f((float)e.acc[m], -1.0f, 1.0f);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) o[9 + m] = pdiff_f[m];
+    }
+    if (KIND != 1) {
+        float *op = KIND == 2 ? o : o + 13;
+#pragma unroll
+        for (int m = 0; m < 5; ++m) {
+            op[m] = lvl_f[m];
+            op[5 + m] = lvl_f[m];
+        }
+        op[10] = frac.x;
+        op[11] = frac.y;
+        op[12] = frac.z;
+        op[13] = frac.w;
+        op[14] = timer_f[0];
+        op[15] = timer_f[1];
+    }
+
     e.step += 1;
+    if (check_overflow && over) { // env_super.py:900-905 + the variants' early return: the press reward is
+        // not evaluated there, so the latched _last_press_* flags survive
+        r.reward = tb.cst[CST_OVERFLOW_PEN];
+        r.done = 1;
+        return r;
+    }
+    r.reward = KIND == 1 ? tanh_v : (KIND == 2 ? rp : tanh_v + rp);
     r.done = e.step >= P.max_steps ? 1 : 0;
     return r;
 }

@@ -74,21 +74,19 @@ __device__ __forceinline__ void stage_and_store(uint8_t *lds_base, const float *
     if (gobs != nullptr) {
         float *g = gobs + wave * 64 * D;
         const int total = n_valid * D;
-        if ((reinterpret_cast<uintptr_t>(g) & 15u) == 0) {
-            // all LDS reads first, then the 16-byte stores: one LDS latency per tile instead of one per piece
-            constexpr int NV = (64 * D / 4 + 63) / 64;
-            const int nvec = total >> 2;
+        constexpr int NQ = 64 * D / 4;       // 16-byte pieces of a full tile (64 rows)
+        constexpr int NFULL = NQ / 64;       // rounds in which every lane moves one piece
+        constexpr int NTAIL = NQ - 64 * NFULL;
+        if (n_valid == 64 && (reinterpret_cast<uintptr_t>(g) & 15u) == 0) {
+            // full tile: all LDS reads first (unconditional), then the 16-byte stores
             const float4 *src = reinterpret_cast<const float4 *>(lobs);
             float4 *dst = reinterpret_cast<float4 *>(g);
-            float4 buf[NV];
+            float4 buf[NFULL + 1];
 #pragma unroll
-            for (int j = 0; j < NV; ++j) buf[j] = src[lane + 64 * j]; // past the tile: still inside the LDS image, unused
+            for (int j = 0; j <= NFULL; ++j) buf[j] = src[lane + 64 * j]; // the last one may run past the tile: unused
 #pragma unroll
-            for (int j = 0; j < NV; ++j) {
-                const int v = lane + 64 * j;
-                if (v < nvec) dst[v] = buf[j];
-            }
-            for (int q = (nvec << 2) + lane; q < total; q += 64) g[q] = lobs[q];
+            for (int j = 0; j < NFULL; ++j) dst[lane + 64 * j] = buf[j];
+            if (NTAIL > 0 && lane < NTAIL) dst[lane + 64 * NFULL] = buf[NFULL];
         } else {
             for (int q = lane; q < total; q += 64) g[q] = lobs[q];
         }
@@ -96,12 +94,14 @@ __device__ __forceinline__ void stage_and_store(uint8_t *lds_base, const float *
     if (gmask != nullptr) {
         uint8_t *g = gmask + wave * 64 * A;
         const int total = n_valid * A;
-        if ((reinterpret_cast<uintptr_t>(g) & 15u) == 0) {
-            const int nvec = total >> 4;
+        constexpr int NQ = 64 * A / 16; // whole 16-byte pieces of a full tile (64 * A is a multiple of 16 for even A)
+        if (n_valid == 64 && (64 * A) % 16 == 0 && NQ <= 128 && (reinterpret_cast<uintptr_t>(g) & 15u) == 0) {
             const uint4 *src = reinterpret_cast<const uint4 *>(lmask);
             uint4 *dst = reinterpret_cast<uint4 *>(g);
-            for (int v = lane; v < nvec; v += 64) dst[v] = src[v];
-            for (int q = (nvec << 4) + lane; q < total; q += 64) g[q] = lmask[q];
+            const uint4 b0 = src[lane];
+            const uint4 b1 = src[lane + 64]; // may run past the tile: unused
+            if (lane < NQ) dst[lane] = b0;
+            if (NQ > 64 && lane + 64 < NQ) dst[lane + 64] = b1;
         } else {
             for (int q = lane; q < total; q += 64) g[q] = lmask[q];
         }
@@ -110,11 +110,11 @@ __device__ __forceinline__ void stage_and_store(uint8_t *lds_base, const float *
 }
 
 // auto-reset of a finished episode inside the step (reset(seed=None) semantics: streams continue)
-__device__ __forceinline__ void auto_reset_env(Env &e, const Params &P, const BaleRef &bales, int k[4])
+__device__ __forceinline__ void auto_reset_env(Env &e, const Params &P, const Tables &tb, const BaleRef &bales, int k[4])
 {
     e.gen2 = unseeded_gen2(e);
     e.episode += 1u;
-    reset_episode_state(e, P);
+    reset_episode_state(e, tb.cst);
     if (P.track_bales) clear_bales(bales);
 #pragma unroll
     for (int m = 0; m < 4; ++m) k[m] = 101; // empty containers
@@ -158,14 +158,13 @@ __global__ __launch_bounds__(kBlock) void k_step(Params P, uint4 *__restrict__ p
         }
         int sm = (KIND == 2 && sort_mode != nullptr) ? sort_mode[i] : -1;
         int k[4];
-        StepResult r = env_step<KIND, NOISE, LITERAL>(e, P, tb, a, sm, flags, bales, k);
-        env_obs<KIND>(e, P, tb, k, o);
+        StepResult r = env_step<KIND, NOISE, LITERAL>(e, P, tb, a, sm, flags, bales, k, o);
         if (r.done && P.auto_reset) {
             if (terminal_obs_out != nullptr) {
 #pragma unroll
                 for (int j = 0; j < D; ++j) terminal_obs_out[i * D + j] = o[j];
             }
-            auto_reset_env(e, P, bales, k);
+            auto_reset_env(e, P, tb, bales, k);
             env_obs<KIND>(e, P, tb, k, o);
         }
         mbits = action_mask_bits<KIND>(e, P);
@@ -228,18 +227,25 @@ __global__ __launch_bounds__(kBlock) void k_rollout(Params P, uint4 *__restrict_
             // masked-uniform policy on the current state (env_monolith.py:152-158 with masking)
             uint32_t cur = action_mask_bits<KIND>(e, P);
             uint32_t cnt = (uint32_t)__popc(cur);
+#ifdef MSE_ABL_NOHASH
+            uint32_t rr = ((uint32_t)i * 2654435761u) ^ ((uint32_t)s * 0x9E3779B9u);
+            rr ^= rr >> 15;
+#else
             uint32_t rr = policy_u32(policy_seed, (uint64_t)(P.index_offset + i), policy_t0 + (uint64_t)s);
+#endif
             int a = select_kth_bit(cur, (int)(((uint64_t)rr * cnt) >> 32));
 #ifdef MSE_ABL_NOPOLICY
             a = (int)(s & 1) * 11;
 #endif
             int k[4];
-            StepResult r = env_step<KIND, NOISE, LITERAL>(e, P, tb, a, sm, flags, bales, k);
-            if (r.done) auto_reset_env(e, P, bales, k);
-#ifndef MSE_ABL_NOOBS
-            env_obs<KIND>(e, P, tb, k, o);
-#endif
+            StepResult r = env_step<KIND, NOISE, LITERAL>(e, P, tb, a, sm, flags, bales, k, o);
+            if (r.done) { // every env of a batch finishes its episode on the same step: rare, wave-uniform
+                auto_reset_env(e, P, tb, bales, k);
+                env_obs<KIND>(e, P, tb, k, o);
+            }
+#ifndef MSE_ABL_NOMASK
             mbits = action_mask_bits<KIND>(e, P);
+#endif
             if (actions_out != nullptr) actions_out[(long long)s * P.n + i] = a;
             if (reward_out != nullptr) reward_out[(long long)s * P.n + i] = (float)r.reward;
             if (done_out != nullptr) done_out[(long long)s * P.n + i] = (uint8_t)r.done;
@@ -288,7 +294,7 @@ __global__ __launch_bounds__(kBlock) void k_reset(Params P, uint4 *__restrict__ 
             e.gen2 = unseeded_gen2(e);
             e.episode += 1u;
         }
-        reset_episode_state(e, P);
+        reset_episode_state(e, tb.cst);
         clear_bales(BaleRef{planes + (long long)PL_BALE0 * P.n_pad + i, P.n_pad});
         store_env<1, true>(e, planes, P, i, reseeded);
     }
@@ -602,6 +608,20 @@ static int build_tables(const mse_config &c, Params &P, std::vector<uint32_t> &i
     P.off_ptime = (int)image.size();
     image.push_back((uint32_t)c.press_time[0]);
     image.push_back((uint32_t)c.press_time[1]);
+    P.off_cst = (int)image.size(); // even: every section so far has an even word count after off_tanh
+    {
+        double cst[CST_COUNT] = {};
+        cst[CST_PEN_CAT] = c.overflow_penalty_catastrophic;
+        cst[CST_PEN_SEV] = c.overflow_penalty_severe;
+        cst[CST_PEN_MILD] = c.overflow_penalty_mild;
+        cst[CST_MAX_STATE] = c.max_state_reward;
+        cst[CST_OVERFLOW_PEN] = c.overflow_termination_penalty;
+        cst[CST_REM_THR] = c.bale_remainder_threshold;
+        cst[CST_BOOST] = c.boost;
+        cst[CST_NOISE] = c.noise;
+        for (int m = 0; m < 4; ++m) cst[CST_BASE_ACC0 + m] = c.baseline_accuracy[m];
+        for (int k = 0; k < CST_COUNT; ++k) put_f64(cst[k]);
+    }
     P.table_words = (int)image.size();
     if (P.table_words > 16384) {
         why = "container_capacity / bale_standard_size too large for the LDS-resident tables (64 KiB)";
@@ -766,17 +786,10 @@ int mse_create_indexed(mse_env **out, const mse_config *cfg, int64_t n_envs, int
     P.capacity = cfg->container_capacity;
     P.stage_capacity = cfg->stage_capacity;
     P.batch = cfg->input_batch_size;
-    P.press_time[0] = cfg->press_time[0];
-    P.press_time[1] = cfg->press_time[1];
-    for (int m = 0; m < 4; ++m) P.base_acc[m] = cfg->baseline_accuracy[m];
-    P.boost = cfg->boost;
-    P.noise = cfg->noise;
-    P.pen_cat = cfg->overflow_penalty_catastrophic;
-    P.pen_sev = cfg->overflow_penalty_severe;
-    P.pen_mild = cfg->overflow_penalty_mild;
+    P.press_time[0] = P.press_time0 = cfg->press_time[0];
+    P.press_time[1] = P.press_time1 = cfg->press_time[1];
+    P.inv_balesize = 1.0f / (float)cfg->bale_standard_size;
     P.max_state_reward = cfg->max_state_reward;
-    P.overflow_pen = cfg->overflow_termination_penalty;
-    P.rem_thr = cfg->bale_remainder_threshold;
     std::vector<uint32_t> image;
     std::string why;
     int trc = build_tables(*cfg, P, image, why);

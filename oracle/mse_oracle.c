@@ -897,8 +897,16 @@ void orc_env_snapshot(const orc_env *e, int64_t *I, double *D, uint64_t *R)
 /* policy word shared with the HIP rollout kernel: see DESIGN.md "random policy" */
 static uint32_t policy_u32(uint64_t seed, uint64_t env_index, uint64_t t)
 {
-    uint64_t x = seed ^ (env_index * 0x9E3779B97F4A7C15ull) ^ (t * 0xD1B54A32D192ED03ull);
-    return (uint32_t)(mix64(x) >> 32);
+    const uint32_t s32 = (uint32_t)seed ^ ((uint32_t)(seed >> 32) * 0x85EBCA6Bu);
+    const uint32_t g32 = (uint32_t)env_index ^ ((uint32_t)(env_index >> 32) * 0xC2B2AE35u);
+    const uint32_t t32 = (uint32_t)t ^ ((uint32_t)(t >> 32) * 0x27D4EB2Fu);
+    uint32_t h = s32 + g32 * 0x9E3779B1u + t32 * 0x85EBCA77u;
+    h ^= h >> 16;
+    h *= 0x85EBCA6Bu;
+    h ^= h >> 13;
+    h *= 0xC2B2AE35u;
+    h ^= h >> 16;
+    return h;
 }
 
 double orc_env_random_rollout(orc_env *e, int64_t n_steps, uint64_t policy_seed)

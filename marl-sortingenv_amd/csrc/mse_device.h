@@ -72,6 +72,7 @@ struct Params {
     // stage vectors are one of three words: id 0 = empty (after reset), 1 / 2 = seasonal pattern
     uint32_t pat_word[3];   // packed u8x4 counts A..D (load/store conversion only; the step reads the LDS copy)
     int thr_sev, thr_mild;  // levels above these have fill_ratio > 0.95 / > 0.90 (literal fp64 scan on the host)
+    int sev_negative, mild_negative; // overflow_penalty_severe / _mild < 0 (then that bracket returns early)
     int k_thr[4];           // hundredths of python round(quality_threshold, 2): purity of an empty container
     // offsets (in 4-byte words) into the table image; see build_tables
     int off_lvl, off_pdiff, off_timer0, off_timer1, off_tanh, off_eff, off_pat, off_acc, off_bonus, off_ptime, off_cst, table_words;
@@ -541,7 +542,7 @@ __device__ __forceinline__ void draw_units(Pcg &rng, uint32_t &C, int &rem)
             flags = ((__umul24(v, 0x010101u) | 0x00808080u) - C) & 0x00808080u; // bytes 0..2 only; v < 128
             literal = (f + 0x200u) < 0x210u; // f < 16 or f >= 2^32 - 512
         }
-        if (literal) {
+        if (__builtin_expect(literal, 0)) { // ~1e-7 per draw: keep it out of the loop's straight line
             const int sel = choice4_literal(C, pcg_output(rng));
             flags = sel == 0 ? 0u : (sel == 1 ? 0x00000080u : (sel == 2 ? 0x00008080u : 0x00808080u));
         }
@@ -776,53 +777,6 @@ __device__ __forceinline__ Tables tables_at(const uint32_t *base, const Params &
     return t;
 }
 
-// env_super.py:963-1003 calculate_sorting_reward: tanh(((sum_m (purity_m - theta)) / 4 * 2) / T).
-// The four purities are hundredths, so the reward is tabulated by their integer sum (the literal
-// fp64 sum differs from the tabulated one by < 1e-15, far inside the 1e-6 reward tolerance).
-__device__ __forceinline__ double sorting_reward(const Params &P, const Tables &tb, const int k[4])
-{
-    int s = 0;
-#pragma unroll
-    for (int m = 0; m < 4; ++m) s += (k[m] == 101) ? P.k_thr[m] : k[m];
-    return tb.tanh_s[s];
-}
-
-// env_super.py:1006-1080 calculate_press_reward
-__device__ __forceinline__ double press_reward(Env &e, const Params &P, const Tables &tb)
-{
-    bool any_cat = false, any_sev = false, any_mild = false;
-    int total_level = 0;
-#pragma unroll
-    for (int m = 0; m < 5; ++m) {
-        int lvl = level_of(e, m);
-        total_level += lvl;
-        bool cat = lvl > P.capacity;                  // fill_ratio > 1.0
-        bool sev = !cat && lvl > P.thr_sev;           // elif fill_ratio > 0.95
-        bool mild = !cat && !sev && lvl > P.thr_mild; // elif fill_ratio > 0.90
-        any_cat |= cat;
-        any_sev |= sev;
-        any_mild |= mild;
-    }
-    if (any_cat) return tb.cst[CST_PEN_CAT];
-    double max_pen = 0.0;
-    if (any_sev) max_pen = fmin(max_pen, tb.cst[CST_PEN_SEV]);
-    if (any_mild) max_pen = fmin(max_pen, tb.cst[CST_PEN_MILD]);
-    if (max_pen < 0.0) return max_pen;
-    double state_reward = ((double)total_level / (double)(5 * P.capacity)) * tb.cst[CST_MAX_STATE];
-    double action_reward = 0.0;
-    if (e.lps) {
-        const int S = P.balesize;
-        int nb = (int)floor((double)e.lpa / (double)S); // exact for int32 operands
-        int rem = e.lpa - nb * S;
-        int dist = rem < S - rem ? rem : S - rem;
-        action_reward = tb.eff[dist] + tb.bonus[nb < 0 ? 0 : (nb > 3 ? 3 : nb)];
-        e.lps = 0;
-        e.lpa = 0;
-    }
-    double r = state_reward + action_reward;
-    return r < -1.0 ? -1.0 : (r > 1.0 ? 1.0 : r);
-}
-
 __device__ __forceinline__ float clip_f(float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
 // env_super.py:306-325 get_sort_obs -> o[0..12]
@@ -925,10 +879,6 @@ __device__ __forceinline__ void clear_bales(const BaleRef &bales)
     for (int m = 0; m < 5; ++m) *bales.cell(m) = make_uint4(0, 0, 0, 0);
 }
 
-struct StepResult {
-    double reward;
-    int done;
-};
 
 // amount // S and amount % S for 0 <= amount < 2^24 without a division: fp32 estimate, exact fix-up
 __device__ __forceinline__ void divmod_small(int amount, int S, float inv_S, int &q, int &r)
@@ -944,16 +894,47 @@ __device__ __forceinline__ void divmod_small(int amount, int S, float inv_S, int
     }
 }
 
-// One env transition: env_1_sort.py:97-154 / env_2_press.py:88-165 / env_monolith.py:109-284.
-// Returns the reward and done flag, the post-step purities k[] (hundredths) and the post-step
-// observation o[] (before any auto-reset).
-//
-// Table reads are issued in two batches and consumed behind fp64 divisions: at one wave per SIMD an
-// LDS read that is waited for right after its issue costs the full ~150-cycle round trip (the v3
-// profile had ~25 such waits per step, 38 % of the wave's cycles).
+// What the reward / observation side needs of an env after its dynamics ran (before any auto-reset).
+// One env transition = env_dynamics (state-critical: flow, accuracy, sort_material, presses, flag
+// bookkeeping) followed by env_observe (pure function of the snapshot: purities, rewards, observation).
+// The single-role kernels run both in one lane; the pipelined rollout kernel runs them in different
+// waves and passes the snapshot through LDS.
+struct Snap {
+    int ct[4], cf[4], ce;
+    int timer[2];
+    int st_belt, st_sort;
+    int lps, lpa;    // _last_press_started / _amount as calculate_press_reward finds them
+    int mode;        // 0 | 1 | 2 (no boost): selects accuracy_belt when noise == 0
+    double acc[4];   // accuracy_belt (noise > 0)
+    int done;        // terminated after this step
+    int overflowed;  // check_overflow fired: reward = overflow_termination_penalty
+};
+
+struct PenaltyClass {
+    bool any_cat, any_sev, any_mild;
+};
+
+// fill_ratio brackets of calculate_press_reward (env_super.py:1015-1030) on integer levels
+__device__ __forceinline__ PenaltyClass classify_levels(const int lvl[5], const Params &P)
+{
+    PenaltyClass c{false, false, false};
+#pragma unroll
+    for (int m = 0; m < 5; ++m) {
+        const bool cat = lvl[m] > P.capacity;                  // fill_ratio > 1.0
+        const bool sev = !cat && lvl[m] > P.thr_sev;           // elif fill_ratio > 0.95
+        const bool mild = !cat && !sev && lvl[m] > P.thr_mild; // elif fill_ratio > 0.90
+        c.any_cat |= cat;
+        c.any_sev |= sev;
+        c.any_mild |= mild;
+    }
+    return c;
+}
+
+// env_1_sort.py:97-154 / env_2_press.py:88-165 / env_monolith.py:109-284 up to (not including) the reward
+// and observation, plus the state side effects of calculate_press_reward and the step counter.
 template <int KIND, bool NOISE, bool LITERAL>
-__device__ __forceinline__ StepResult env_step(Env &e, const Params &P, const Tables &tb, int action, int sort_mode_in,
-                                               uint32_t flags, const BaleRef &bales, int k[4], float *o)
+__device__ __forceinline__ void env_dynamics(Env &e, const Params &P, const Tables &tb, int action, int sort_mode_in,
+                                             uint32_t flags, const BaleRef &bales, Snap &sn)
 {
     const bool unmasked = (flags & 1u) != 0;
     const bool check_overflow = (flags & 2u) != 0;
@@ -995,29 +976,81 @@ __device__ __forceinline__ StepResult env_step(Env &e, const Params &P, const Ta
     if (run_press_rules) press_action_rules(e, P, tb.cst, press_action, bales);
 #endif
 
-    // ---- batch A: everything that needs only the post-press integer state -----------------------
+    // snapshot for the observer
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        sn.ct[m] = e.ct[m];
+        sn.cf[m] = e.cf[m];
+        sn.acc[m] = e.acc[m];
+    }
+    sn.ce = e.ce;
+    sn.timer[0] = e.timer[0];
+    sn.timer[1] = e.timer[1];
+    sn.st_belt = e.st_belt;
+    sn.st_sort = e.st_sort;
+    sn.lps = e.lps;
+    sn.lpa = e.lpa;
+    sn.mode = e.mode == 0 ? 0 : (e.mode == 1 ? 1 : 2);
+
+    // state side of the rewards: overflow termination (env_super.py:900-905) and the clearing of
+    // _last_press_* by calculate_press_reward unless it returned a penalty first (env_super.py:1022-1030,1073-1075)
     int lvl[5];
 #pragma unroll
     for (int m = 0; m < 5; ++m) lvl[m] = level_of(e, m);
+    const PenaltyClass pc = classify_levels(lvl, P);
+    const bool overflowed = check_overflow && pc.any_cat; // a level above capacity
+    if (KIND != 1 && !overflowed) {
+        const bool penalised = pc.any_cat || (pc.any_sev && P.sev_negative) || (pc.any_mild && P.mild_negative);
+        if (!penalised) {
+            e.lps = 0;
+            e.lpa = 0;
+        }
+    }
+    e.step += 1;
+    sn.overflowed = overflowed ? 1 : 0;
+    sn.done = (overflowed || e.step >= P.max_steps) ? 1 : 0;
+}
+
+struct StepResult {
+    double reward;
+    int done;
+};
+
+// Rewards (env_super.py:963-1080) and observation (env_super.py:306-359) of a snapshot; k[] returns the
+// container purities in hundredths ([101] = empty).
+//
+// Table reads are issued in two batches and consumed behind fp64 divisions: at one wave per SIMD an
+// LDS read that is waited for right after its issue costs the full round trip.
+template <int KIND, bool NOISE>
+__device__ __forceinline__ StepResult env_observe(const Snap &sn, const Params &P, const Tables &tb, int k[4], float *o)
+{
+    // ---- batch A: everything that needs only the integer state -----------------------------------
+    int lvl[5];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) lvl[m] = sn.ct[m] + sn.cf[m];
+    lvl[4] = sn.ce;
     float lvl_f[5], timer_f[2], occ_f = 0.0f;
     float4 prop = make_float4(0.f, 0.f, 0.f, 0.f), frac = prop;
     if (KIND != 1) { // get_press_obs pieces (env_super.py:327-359)
 #pragma unroll
         for (int m = 0; m < 5; ++m) lvl_f[m] = tb.lvl[lvl[m] < P.capacity ? lvl[m] : P.capacity];
-        timer_f[0] = tb.timer0[e.timer[0]];
-        timer_f[1] = tb.timer1[e.timer[1]];
-        frac = *reinterpret_cast<const float4 *>(tb.pat + e.st_sort * kPatStride + 8);
+        timer_f[0] = tb.timer0[sn.timer[0]];
+        timer_f[1] = tb.timer1[sn.timer[1]];
+        frac = *reinterpret_cast<const float4 *>(tb.pat + sn.st_sort * kPatStride + 8);
     }
+    double acc[4];
     if (KIND != 2) { // get_sort_obs pieces (env_super.py:306-325)
-        const uint32_t *rec = tb.pat + e.st_belt * kPatStride;
+        const uint32_t *rec = tb.pat + sn.st_belt * kPatStride;
         occ_f = __uint_as_float(rec[1]);
         prop = *reinterpret_cast<const float4 *>(rec + 4);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) acc[m] = NOISE ? sn.acc[m] : tb.acc[4 * sn.mode + m];
     }
     // action part of calculate_press_reward (env_super.py:1052-1075), branch-free: without a started
     // press the amount is 0 and the looked-up value is discarded
     double eff_v = 0.0, bonus_v = 0.0;
     if (KIND != 1) {
-        const int amount = e.lps ? e.lpa : 0;
+        const int amount = sn.lps ? sn.lpa : 0;
         int nb, rem;
         divmod_small(amount, P.balesize, P.inv_balesize, nb, rem);
         const int dist = rem < P.balesize - rem ? rem : P.balesize - rem;
@@ -1025,15 +1058,16 @@ __device__ __forceinline__ StepResult env_step(Env &e, const Params &P, const Ta
         bonus_v = tb.bonus[nb > 3 ? 3 : nb];
     }
 
-    // ---- purity: four fp64 divisions (they also cover batch A's LDS latency) ---------------------
-    StepResult r;
+    // ---- purity: four fp64 divisions (they also cover batch A's LDS latency) ----------------------
+    // env_super.py:771-791; round(true/total, 2) in hundredths, [101] = empty container
 #ifdef MSE_ABL_NOREWARD
     k[0] = k[1] = k[2] = k[3] = 101;
 #else
-    container_purity_k(e, k);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) k[m] = lvl[m] > 0 ? purity_hundredths(sn.ct[m], lvl[m]) : 101;
 #endif
 
-    // ---- batch B: reads keyed by the purities ---------------------------------------------------
+    // ---- batch B: reads keyed by the purities -------------------------------------------------------
     float pdiff_f[4] = {0.f, 0.f, 0.f, 0.f};
     double tanh_v = 0.0;
     if (KIND != 2) {
@@ -1042,57 +1076,40 @@ __device__ __forceinline__ StepResult env_step(Env &e, const Params &P, const Ta
         int s = 0;
 #pragma unroll
         for (int m = 0; m < 4; ++m) s += (k[m] == 101) ? P.k_thr[m] : k[m];
-        tanh_v = tb.tanh_s[s]; // calculate_sorting_reward (env_super.py:963-1003), see Tables::tanh_s
+        // calculate_sorting_reward (env_super.py:963-1003) tabulated by the integer sum of the four purity
+        // hundredths (the literal fp64 sum differs from the tabulated one by < 1e-15)
+        tanh_v = tb.tanh_s[s];
     }
 
-    // ---- calculate_press_reward (env_super.py:1006-1080); its division covers batch B ------------
+    // ---- calculate_press_reward (env_super.py:1006-1080); its division covers batch B --------------
     double rp = 0.0;
-    bool over = false;
     if (KIND != 1) {
-        bool any_cat = false, any_sev = false, any_mild = false;
-        int total_level = 0;
-#pragma unroll
-        for (int m = 0; m < 5; ++m) {
-            total_level += lvl[m];
-            const bool cat = lvl[m] > P.capacity;                  // fill_ratio > 1.0
-            const bool sev = !cat && lvl[m] > P.thr_sev;           // elif fill_ratio > 0.95
-            const bool mild = !cat && !sev && lvl[m] > P.thr_mild; // elif fill_ratio > 0.90
-            any_cat |= cat;
-            any_sev |= sev;
-            any_mild |= mild;
-        }
-        over = any_cat;
+        const PenaltyClass pc = classify_levels(lvl, P);
+        const int total_level = lvl[0] + lvl[1] + lvl[2] + lvl[3] + lvl[4];
         const double state_reward = ((double)total_level / (double)(5 * P.capacity)) * P.max_state_reward;
-        // penalty returns (env_super.py:1022-1030) happen BEFORE the flags are cleared: _last_press_* stay latched
-        bool penalised = any_cat;
+        bool penalised = pc.any_cat;
         double penalty = 0.0;
-        if (any_cat || any_sev || any_mild) { // rare: the constants are fetched only here
+        if (__builtin_expect(pc.any_cat || pc.any_sev || pc.any_mild, 0)) { // rare: constants fetched only here
             double max_pen = 0.0;
-            if (any_sev) max_pen = fmin(max_pen, tb.cst[CST_PEN_SEV]);
-            if (any_mild) max_pen = fmin(max_pen, tb.cst[CST_PEN_MILD]);
-            penalty = any_cat ? tb.cst[CST_PEN_CAT] : max_pen;
-            penalised = any_cat || max_pen < 0.0;
+            if (pc.any_sev) max_pen = fmin(max_pen, tb.cst[CST_PEN_SEV]);
+            if (pc.any_mild) max_pen = fmin(max_pen, tb.cst[CST_PEN_MILD]);
+            penalty = pc.any_cat ? tb.cst[CST_PEN_CAT] : max_pen;
+            penalised = pc.any_cat || max_pen < 0.0;
         }
         if (penalised) {
             rp = penalty;
         } else {
-            const double ar = e.lps ? eff_v + bonus_v : 0.0;
+            const double ar = sn.lps ? eff_v + bonus_v : 0.0;
             const double v = state_reward + ar;
             rp = v < -1.0 ? -1.0 : (v > 1.0 ? 1.0 : v);
-            e.lps = 0;
-            e.lpa = 0;
         }
-    }
-    if (KIND == 1) {
-#pragma unroll
-        for (int m = 0; m < 5; ++m) over = over || (lvl[m] > P.capacity);
     }
 #ifdef MSE_ABL_NOREWARD
     rp = 0.0;
     tanh_v = 0.0;
 #endif
 
-    // ---- observation (env_super.py:306-359) ------------------------------------------------------
+    // ---- observation (env_super.py:306-359) ---------------------------------------------------------
     if (KIND != 2) {
         o[0] = occ_f;
         o[1] = prop.x;
@@ -1100,7 +1117,7 @@ __device__ __forceinline__ StepResult env_step(Env &e, const Params &P, const Ta
         o[3] = prop.z;
         o[4] = prop.w;
 #pragma unroll
-        for (int m = 0; m < 4; ++m) o[5 + m] = clip_f((float)e.acc[m], -1.0f, 1.0f);
+        for (int m = 0; m < 4; ++m) o[5 + m] = clip_f((float)acc[m], -1.0f, 1.0f);
 #pragma unroll
         for (int m = 0; m < 4; ++m) o[9 + m] = pdiff_f[m];
     }
@@ -1119,16 +1136,41 @@ __device__ __forceinline__ StepResult env_step(Env &e, const Params &P, const Ta
         op[15] = timer_f[1];
     }
 
-    e.step += 1;
-    if (check_overflow && over) { // env_super.py:900-905 + the variants' early return: the press reward is
-        // not evaluated there, so the latched _last_press_* flags survive
-        r.reward = tb.cst[CST_OVERFLOW_PEN];
-        r.done = 1;
-        return r;
-    }
+    StepResult r;
+    r.done = sn.done;
     r.reward = KIND == 1 ? tanh_v : (KIND == 2 ? rp : tanh_v + rp);
-    r.done = e.step >= P.max_steps ? 1 : 0;
+    // env_super.py:900-905 + the variants' early return: the overflow penalty replaces the rewards
+    if (__builtin_expect(sn.overflowed != 0, 0)) r.reward = tb.cst[CST_OVERFLOW_PEN];
     return r;
+}
+
+// the snapshot of a freshly reset env (observation after an auto-reset)
+__device__ __forceinline__ void snap_of_reset(Snap &sn, const double *cst)
+{
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        sn.ct[m] = 0;
+        sn.cf[m] = 0;
+        sn.acc[m] = cst[CST_BASE_ACC0 + m];
+    }
+    sn.ce = 0;
+    sn.timer[0] = sn.timer[1] = 0;
+    sn.st_belt = sn.st_sort = 0;
+    sn.lps = 0;
+    sn.lpa = 0;
+    sn.mode = 2;
+    sn.done = 0;
+    sn.overflowed = 0;
+}
+
+// one env transition in one lane
+template <int KIND, bool NOISE, bool LITERAL>
+__device__ __forceinline__ StepResult env_step(Env &e, const Params &P, const Tables &tb, int action, int sort_mode_in,
+                                               uint32_t flags, const BaleRef &bales, int k[4], float *o)
+{
+    Snap sn;
+    env_dynamics<KIND, NOISE, LITERAL>(e, P, tb, action, sort_mode_in, flags, bales, sn);
+    return env_observe<KIND, NOISE>(sn, P, tb, k, o);
 }
 
 } // namespace mse

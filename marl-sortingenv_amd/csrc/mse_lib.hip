@@ -239,7 +239,7 @@ __global__ __launch_bounds__(kBlock) void k_rollout(Params P, uint4 *__restrict_
 #endif
             int k[4];
             StepResult r = env_step<KIND, NOISE, LITERAL>(e, P, tb, a, sm, flags, bales, k, o);
-            if (r.done) { // every env of a batch finishes its episode on the same step: rare, wave-uniform
+            if (__builtin_expect(r.done != 0, 0)) { // every env of a batch finishes its episode on the same step: rare, wave-uniform
                 auto_reset_env(e, P, tb, bales, k);
                 env_obs<KIND>(e, P, tb, k, o);
             }
@@ -542,6 +542,8 @@ static int build_tables(const mse_config &c, Params &P, std::vector<uint32_t> &i
         return MSE_ERR_UNSUPPORTED_CONFIG;
     }
     // fill_ratio thresholds of calculate_press_reward as integer levels (env_super.py:1020-1027)
+    P.sev_negative = c.overflow_penalty_severe < 0.0 ? 1 : 0;
+    P.mild_negative = c.overflow_penalty_mild < 0.0 ? 1 : 0;
     P.thr_sev = P.thr_mild = cap;
     for (int L = cap; L >= 0; --L) {
         double fill = (double)L / (double)cap;

@@ -86,6 +86,10 @@ typedef struct mse_config {
     double   overflow_termination_penalty;
     /* seasonal patterns 1 and 2, order A,B,C,D (utils/input_generator.py:17-20) */
     double   pattern_ratio[2][4];
+    /* mse_rollout kernel choice: 0 = by size (pipelined dynamics/observer waves up to 131 072 envs, one lane per
+       env above), 1 = always pipelined, 2 = never.  Results are identical either way. */
+    int32_t  rollout_pipeline;
+    int32_t  reserved0;
 } mse_config;
 
 typedef struct mse_env mse_env; /* opaque handle: N envs on one device */

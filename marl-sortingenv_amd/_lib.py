@@ -40,6 +40,7 @@ class MseConfigStruct(C.Structure):
         ("overflow_penalty_mild", C.c_double), ("bale_efficiency_factor", C.c_double),
         ("max_state_reward", C.c_double), ("overflow_termination_penalty", C.c_double),
         ("pattern_ratio", (C.c_double * 4) * 2),
+        ("rollout_pipeline", C.c_int32), ("reserved0", C.c_int32),
     ]
 
 

@@ -34,7 +34,7 @@ class BatchedSortingEnv:
                  noise_sorting: Optional[float] = 0.05, balesize: Optional[int] = 200,
                  config: Optional[SortingEnvConfig] = None, auto_reset: bool = True,
                  track_bales: bool = True, literal_choice: bool = False, index_offset: int = 0,
-                 reset_now: bool = True):
+                 reset_now: bool = True, rollout_pipeline: int = 0):
         if kind not in OBS_DIM:
             raise ValueError(f"kind must be one of {sorted(OBS_DIM)}")
         if not torch.cuda.is_available():
@@ -48,7 +48,7 @@ class BatchedSortingEnv:
         self.index_offset = int(index_offset)
         self.obs_dim, self.num_actions = OBS_DIM[kind], NUM_ACTIONS[kind]
         self._cfg_struct = self.config.to_struct(kind, max_steps, noise_sorting, balesize, auto_reset,
-                                                 track_bales, literal_choice)
+                                                 track_bales, literal_choice, rollout_pipeline)
         self.auto_reset = bool(auto_reset)
         h = C.c_void_p()
         dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()

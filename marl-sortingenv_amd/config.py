@@ -76,7 +76,8 @@ class SortingEnvConfig:
         )
 
     def to_struct(self, kind: str, max_steps: int = 50, noise_sorting=None, balesize=None,
-                  auto_reset: bool = True, track_bales: bool = True, literal_choice: bool = False) -> MseConfigStruct:
+                  auto_reset: bool = True, track_bales: bool = True, literal_choice: bool = False,
+                  rollout_pipeline: int = 0) -> MseConfigStruct:
         import ctypes as C
 
         s = MseConfigStruct()
@@ -86,6 +87,7 @@ class SortingEnvConfig:
         s.auto_reset = int(bool(auto_reset))
         s.track_bales = int(bool(track_bales))
         s.literal_choice = int(bool(literal_choice))
+        s.rollout_pipeline = int(rollout_pipeline)
         s.input_batch_size = int(self.input_batch_size)
         s.steps_per_pattern = int(self.steps_per_pattern)
         for m in range(4):

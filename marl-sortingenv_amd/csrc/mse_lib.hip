@@ -36,6 +36,12 @@ struct LdsLayout {
     static constexpr int table_offset_rollout = bale_offset + bale_bytes;
 };
 
+// workgroup barrier that waits for this wave's LDS traffic only (global stores stay in flight)
+__device__ __forceinline__ void lds_barrier_all()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 __device__ __forceinline__ void load_tables_to_lds(uint32_t *dst, const uint32_t *__restrict__ src, int words, int tid)
 {
     for (int w = tid; w < words; w += kBlock) dst[w] = src[w];
@@ -47,14 +53,14 @@ __device__ __forceinline__ void load_tables_to_lds(uint32_t *dst, const uint32_t
 // instructions in order, so no workgroup barrier is needed (the first profile showed 36 % of wave time
 // parked at the per-step barriers).  gobs / gmask point at the WORKGROUP's first row.
 template <int KIND>
-__device__ __forceinline__ void stage_and_store(uint8_t *lds_base, const float *o, uint32_t mbits, float *gobs,
-                                                uint8_t *gmask, int n_valid_block, int tid)
+__device__ __forceinline__ void stage_and_store(uint8_t *lds_base, int mask_offset, const float *o, uint32_t mbits,
+                                                float *gobs, uint8_t *gmask, int n_valid_block, int tid)
 {
     constexpr int D = Dims<KIND>::D, A = Dims<KIND>::A;
     const int wave = tid >> 6, lane = tid & 63;
     const int n_valid = min(max(n_valid_block - wave * 64, 0), 64);
     float *lobs = reinterpret_cast<float *>(lds_base) + wave * 64 * D;
-    uint8_t *lmask = lds_base + LdsLayout<KIND>::obs_bytes + wave * 64 * A;
+    uint8_t *lmask = lds_base + mask_offset + wave * 64 * A;
     if (gobs != nullptr) {
 #pragma unroll
         for (int j = 0; j < D; ++j) lobs[lane * D + j] = o[j];
@@ -175,8 +181,8 @@ __global__ __launch_bounds__(kBlock) void k_step(Params P, uint4 *__restrict__ p
     }
     long long rem = P.n - row0;
     const int n_valid = rem >= kBlock ? kBlock : (rem > 0 ? (int)rem : 0);
-    stage_and_store<KIND>(lds, o, mbits, obs_out ? obs_out + row0 * D : nullptr, mask_out ? mask_out + row0 * A : nullptr,
-                          n_valid, tid);
+    stage_and_store<KIND>(lds, LdsLayout<KIND>::obs_bytes, o, mbits, obs_out ? obs_out + row0 * D : nullptr,
+                          mask_out ? mask_out + row0 * A : nullptr, n_valid, tid);
 }
 
 template <int KIND, bool NOISE, bool LITERAL>
@@ -250,13 +256,184 @@ __global__ __launch_bounds__(kBlock) void k_rollout(Params P, uint4 *__restrict_
             if (reward_out != nullptr) reward_out[(long long)s * P.n + i] = (float)r.reward;
             if (done_out != nullptr) done_out[(long long)s * P.n + i] = (uint8_t)r.done;
         }
-        stage_and_store<KIND>(lds, o, mbits, obs_out ? obs_out + srow * D : nullptr,
+        stage_and_store<KIND>(lds, LdsLayout<KIND>::obs_bytes, o, mbits, obs_out ? obs_out + srow * D : nullptr,
                               mask_out ? mask_out + srow * A : nullptr, n_valid, tid);
     }
     if (live) store_env<KIND, NOISE>(e, planes, P, i, false);
     if (P.track_bales) {
 #pragma unroll
         for (int m = 0; m < 5; ++m) planes[(long long)(PL_BALE0 + m) * P.n_pad + i] = lbale[m * kBlock + tid];
+    }
+}
+
+// ==========================================================================================
+// Pipelined rollout: dynamics waves + observer waves  (DESIGN.md "Pipelined rollout")
+//
+// At 65 536 envs a one-lane-per-env grid is exactly one wave per SIMD, and a single wave issues one
+// VALU instruction per ~5 cycles (2-cycle peak).  Here a workgroup of 512 threads serves 256 envs:
+// waves 0-3 run env_dynamics (policy, flow, draws, presses) and hand a snapshot of each env through LDS
+// to waves 4-7, which run env_observe (purities, rewards, observation, mask bytes) and stream the outputs.
+// One s_barrier per step; the snapshot is double buffered, so the dynamics waves run at most one step
+// ahead and never overwrite a buffer the observers still read:
+//     D: [step s dynamics][write snap s%2][barrier B_s][step s+1 ...]
+//     O:                                  [barrier B_s][read snap s%2][outputs of step s][barrier B_{s+1}]
+// Every wave executes exactly k_steps barriers.
+// ==========================================================================================
+constexpr int kPoEnvs = 256;                 // envs per workgroup
+constexpr int kPoThreads = 2 * kPoEnvs;      // waves 0-3 dynamics, waves 4-7 observers: a workgroup's waves go round the
+                                             // CU's four SIMDs, so wave w and wave w+4 share one - each SIMD gets one
+                                             // multiply-heavy dynamics wave and one observer wave
+constexpr int kSnapWordsBase = 13;           // ct[4] cf[4] ce lpa packed action mask
+constexpr int kSnapWordsNoise = kSnapWordsBase + 8; // + accuracy_belt (4 x f64)
+
+template <int KIND, bool NOISE>
+struct PoLayout {
+    static constexpr int D = Dims<KIND>::D, A = Dims<KIND>::A;
+    static constexpr int snap_words = NOISE ? kSnapWordsNoise : kSnapWordsBase;
+    static constexpr int obs_bytes = kPoEnvs * D * 4;
+    static constexpr int mask_bytes = (kPoEnvs * A + 15) / 16 * 16;
+    static constexpr int snap_offset = obs_bytes + mask_bytes;
+    static constexpr int snap_bytes = 2 * snap_words * kPoEnvs * 4;
+    static constexpr int bale_offset = snap_offset + snap_bytes;
+    static constexpr int bale_bytes = 5 * kPoEnvs * 16;
+    static constexpr int table_offset = bale_offset + bale_bytes; // multiple of 16
+};
+
+template <int KIND, bool NOISE, bool LITERAL>
+__global__ __launch_bounds__(kPoThreads) void k_rollout_po(Params P, uint4 *__restrict__ planes,
+                                                       const uint32_t *__restrict__ table_image, int k_steps,
+                                                       uint64_t policy_seed, uint64_t policy_t0,
+                                                       const int *__restrict__ sort_mode, uint32_t flags,
+                                                       int *__restrict__ actions_out, float *__restrict__ obs_out,
+                                                       float *__restrict__ reward_out, uint8_t *__restrict__ done_out,
+                                                       uint8_t *__restrict__ mask_out)
+{
+    using L = PoLayout<KIND, NOISE>;
+    constexpr int D = L::D, A = L::A, SW = L::snap_words;
+    uint8_t *lds = reinterpret_cast<uint8_t *>(mse_dyn_lds);
+    uint32_t *ltab = reinterpret_cast<uint32_t *>(lds + L::table_offset);
+    uint32_t *lsnap = reinterpret_cast<uint32_t *>(lds + L::snap_offset);
+    uint4 *lbale = reinterpret_cast<uint4 *>(lds + L::bale_offset);
+    const int tid = threadIdx.x;
+    const bool observer = tid >= kPoEnvs;            // wave-uniform: waves 0-3 dynamics, waves 4-7 observers
+    const int el = tid & (kPoEnvs - 1);              // env slot inside the workgroup (same for both roles)
+    const long long row0 = (long long)blockIdx.x * kPoEnvs;
+    const long long i = row0 + el;                   // < n_pad always (planes are padded to 256 envs)
+    const bool live = i < P.n;
+
+    for (int w = tid; w < P.table_words; w += kPoThreads) ltab[w] = table_image[w];
+    __syncthreads();
+    const Tables tb = tables_at(ltab, P);
+
+    if (!observer) {
+        // ------------------------------------------------------------------ dynamics waves
+        const BaleRef bales{lbale + el, kPoEnvs};
+        if (P.track_bales) {
+#pragma unroll
+            for (int m = 0; m < 5; ++m) lbale[m * kPoEnvs + el] = planes[(long long)(PL_BALE0 + m) * P.n_pad + i];
+        }
+        Env e;
+        int sm = -1;
+        if (live) {
+            load_env<KIND, NOISE>(e, planes, P, i);
+            if (KIND == 2 && sort_mode != nullptr) sm = sort_mode[i];
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): no load is outstanding inside the step loop
+        for (int s = 0; s < k_steps; ++s) {
+            // padding lanes (i >= n) hold no env: an all-zero PCG64 never leaves zero and would spin forever in
+            // the Lemire rejection loop, so they only keep the barrier count
+            if (live) {
+                // masked-uniform policy on the current state (env_monolith.py:152-158 with masking)
+                const uint32_t cur = action_mask_bits<KIND>(e, P);
+                const uint32_t cnt = (uint32_t)__popc(cur);
+                const uint32_t rr = policy_u32(policy_seed, (uint64_t)(P.index_offset + i), policy_t0 + (uint64_t)s);
+                const int a = select_kth_bit(cur, (int)(((uint64_t)rr * cnt) >> 32));
+                Snap sn;
+                env_dynamics<KIND, NOISE, LITERAL>(e, P, tb, a, sm, flags, bales, sn);
+                if (__builtin_expect(sn.done != 0, 0)) { // all envs of a batch finish together: rare, wave-uniform
+                    int kdummy[4];
+                    auto_reset_env(e, P, tb, bales, kdummy);
+                }
+                const uint32_t mbits = action_mask_bits<KIND>(e, P); // what the next action sees (after auto-reset)
+                uint32_t *w = lsnap + (s & 1) * SW * kPoEnvs + el;
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    w[m * kPoEnvs] = (uint32_t)sn.ct[m];
+                    w[(4 + m) * kPoEnvs] = (uint32_t)sn.cf[m];
+                }
+                w[8 * kPoEnvs] = (uint32_t)sn.ce;
+                w[9 * kPoEnvs] = (uint32_t)sn.lpa;
+                w[10 * kPoEnvs] = (uint32_t)sn.timer[0] | ((uint32_t)sn.timer[1] << 8) | ((uint32_t)sn.st_belt << 16) |
+                                  ((uint32_t)sn.st_sort << 18) | ((uint32_t)sn.mode << 20) | ((uint32_t)sn.lps << 22) |
+                                  ((uint32_t)sn.done << 23) | ((uint32_t)sn.overflowed << 24);
+                w[11 * kPoEnvs] = (uint32_t)a;
+                w[12 * kPoEnvs] = mbits;
+                if (NOISE) {
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) {
+                        w[(13 + 2 * m) * kPoEnvs] = (uint32_t)__double2loint(sn.acc[m]);
+                        w[(14 + 2 * m) * kPoEnvs] = (uint32_t)__double2hiint(sn.acc[m]);
+                    }
+                }
+            }
+            lds_barrier_all(); // B_s
+        }
+        if (live) store_env<KIND, NOISE>(e, planes, P, i, false);
+        if (P.track_bales) {
+#pragma unroll
+            for (int m = 0; m < 5; ++m) planes[(long long)(PL_BALE0 + m) * P.n_pad + i] = lbale[m * kPoEnvs + el];
+        }
+    } else {
+        // ------------------------------------------------------------------ observer waves
+        long long rem = P.n - row0;
+        const int n_valid_block = rem >= kPoEnvs ? kPoEnvs : (rem > 0 ? (int)rem : 0);
+        float o[D];
+#pragma unroll
+        for (int j = 0; j < D; ++j) o[j] = 0.0f;
+        for (int s = 0; s < k_steps; ++s) {
+            lds_barrier_all(); // B_s: the snapshot of step s is complete
+            const uint32_t *w = lsnap + (s & 1) * SW * kPoEnvs + el;
+            Snap sn;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                sn.ct[m] = (int)w[m * kPoEnvs];
+                sn.cf[m] = (int)w[(4 + m) * kPoEnvs];
+            }
+            sn.ce = (int)w[8 * kPoEnvs];
+            sn.lpa = (int)w[9 * kPoEnvs];
+            const uint32_t pk = w[10 * kPoEnvs];
+            const int a = (int)w[11 * kPoEnvs];
+            const uint32_t mbits = w[12 * kPoEnvs];
+            if (NOISE) {
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+                    sn.acc[m] = __hiloint2double((int)w[(14 + 2 * m) * kPoEnvs], (int)w[(13 + 2 * m) * kPoEnvs]);
+            }
+            sn.timer[0] = (int)(pk & 0xFFu);
+            sn.timer[1] = (int)((pk >> 8) & 0xFFu);
+            sn.st_belt = (int)((pk >> 16) & 3u);
+            sn.st_sort = (int)((pk >> 18) & 3u);
+            sn.mode = (int)((pk >> 20) & 3u);
+            sn.lps = (int)((pk >> 22) & 1u);
+            sn.done = (int)((pk >> 23) & 1u);
+            sn.overflowed = (int)((pk >> 24) & 1u);
+            if (live) { // the snapshot slots of padding lanes are never written
+                int k[4];
+                StepResult r = env_observe<KIND, NOISE>(sn, P, tb, k, o);
+                if (__builtin_expect(sn.done != 0, 0)) { // the step's observation is the one after the auto-reset
+                    Snap rs;
+                    snap_of_reset(rs, tb.cst);
+                    int k2[4];
+                    (void)env_observe<KIND, true>(rs, P, tb, k2, o);
+                }
+                if (actions_out != nullptr) actions_out[(long long)s * P.n + i] = a;
+                if (reward_out != nullptr) reward_out[(long long)s * P.n + i] = (float)r.reward;
+                if (done_out != nullptr) done_out[(long long)s * P.n + i] = (uint8_t)r.done;
+            }
+            const long long srow = (long long)s * P.n + row0;
+            stage_and_store<KIND>(lds, L::obs_bytes, o, mbits, obs_out ? obs_out + srow * D : nullptr,
+                                  mask_out ? mask_out + srow * A : nullptr, n_valid_block, tid - kPoEnvs);
+        }
     }
 }
 
@@ -471,6 +648,7 @@ struct mse_env {
     bool seeded;
     bool noise_on;
     bool literal;                // evaluate every Generator.choice draw in literal fp64
+    bool pipelined;              // mse_rollout uses the dynamics/observer kernel (k_rollout_po)
     uint64_t policy_t;
 };
 
@@ -667,6 +845,23 @@ static void launch_rollout(mse_env *h, hipStream_t s, int k_steps, uint64_t poli
                            uint32_t flags, int32_t *actions, float *obs, float *rew, uint8_t *done, uint8_t *mask)
 {
     const bool lit = h->literal;
+    if (h->pipelined) {
+        const dim3 grid((unsigned)(h->P.n_pad / kPoEnvs));
+        const size_t table_bytes = (size_t)h->P.table_words * 4u;
+        const size_t lds_noise = (size_t)PoLayout<KIND, true>::table_offset + table_bytes;
+        const size_t lds_plain = (size_t)PoLayout<KIND, false>::table_offset + table_bytes;
+#define MSE_LAUNCH_PO(NOISE, LIT)                                                                        \
+    hipLaunchKernelGGL((k_rollout_po<KIND, NOISE, LIT>), grid, dim3(kPoThreads), (NOISE ? lds_noise : lds_plain), s, \
+                       h->P, h->planes, h->tables, k_steps, policy_seed, h->policy_t, sort_mode, flags, actions, obs, \
+                       rew, done, mask)
+        if (h->noise_on) {
+            if (lit) MSE_LAUNCH_PO(true, true); else MSE_LAUNCH_PO(true, false);
+        } else {
+            if (lit) MSE_LAUNCH_PO(false, true); else MSE_LAUNCH_PO(false, false);
+        }
+#undef MSE_LAUNCH_PO
+        return;
+    }
     const size_t lds = lds_bytes_rollout<KIND>(h);
 #define MSE_LAUNCH_ROLLOUT(NOISE, LIT)                                                                   \
     hipLaunchKernelGGL((k_rollout<KIND, NOISE, LIT>), grid_of(h), dim3(kBlock), lds, s, h->P, h->planes, h->tables, \
@@ -801,6 +996,9 @@ int mse_create_indexed(mse_env **out, const mse_config *cfg, int64_t n_envs, int
     }
     // the byte-packed integer draw needs every prefix sum below 128; larger batches draw in literal fp64
     h->literal = cfg->literal_choice != 0 || cfg->input_batch_size > 127;
+    // rollout kernel: the pipelined one (dynamics + observer waves) pays off while a one-lane-per-env grid
+    // leaves the SIMDs under two waves each; 0 = decide by size, 1 = always, 2 = never
+    h->pipelined = cfg->rollout_pipeline == 1 || (cfg->rollout_pipeline == 0 && n_envs <= 131072);
 
     size_t bytes = (size_t)PL_COUNT * (size_t)P.n_pad * sizeof(uint4);
     hipError_t e1 = hipMalloc(reinterpret_cast<void **>(&h->planes), bytes);

@@ -167,3 +167,24 @@ def test_full_size_properties(kind, n):
         env2.rollout(K, policy_seed=2024, buffers=buf)
     for x, y in zip(env.get_state(), env2.get_state()):
         assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize("kind", KINDS)
+@pytest.mark.parametrize("noise", [0.0, 0.05])
+def test_pipelined_rollout_equals_single_role_rollout(kind, noise):
+    """mse_rollout's two kernels (dynamics/observer pipeline vs one lane per env) give identical
+    buffers and identical final state; ragged N, several auto-resets, overflow checking on."""
+    import torch
+
+    n, K = 1000 + 37, 45
+    kw = dict(base_seed=321, max_steps=20, noise_sorting=noise, balesize=200, auto_reset=True)
+    a = _mk(kind, n, rollout_pipeline=1, **kw)
+    b = _mk(kind, n, rollout_pipeline=2, **kw)
+    sm = (torch.arange(n, dtype=torch.int32, device="cuda") % 3 - 1) if kind == "press" else None  # -1 = rule
+    for chunk, ovf in ((K, False), (7, True), (1, False)):
+        ra = a.rollout(chunk, policy_seed=11, sort_mode=sm, check_overflow=ovf)
+        rb = b.rollout(chunk, policy_seed=11, sort_mode=sm, check_overflow=ovf)
+        for key in ra:
+            assert torch.equal(ra[key], rb[key]), (key, chunk)
+    for x, y in zip(a.get_state(), b.get_state()):
+        assert torch.equal(x, y)

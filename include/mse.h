@@ -47,6 +47,9 @@ typedef enum mse_env_kind { MSE_ENV_SORT = 1, MSE_ENV_PRESS = 2, MSE_ENV_MONO = 
  * (env_monolith.py:109, env_2_press.py:88, env_1_sort.py:97) */
 #define MSE_STEP_UNMASKED       1u /* use_action_masking=False: validate + sanitise the press action */
 #define MSE_STEP_CHECK_OVERFLOW 2u /* check_overflow=True: overflow terminates with the -10 penalty  */
+/* mse_rollout only: act with the reference's rule-based policy (mode='rule_based', env_monolith.py:166-184:
+ * sorting_rules() env_super.py:469-482 + check_container_level() :689-720) instead of the random one */
+#define MSE_ROLLOUT_RULE_BASED  4u
 
 /* POD copy of the reference's config.yml plus the env constructor arguments
  * (env_super.py:25-137 reads the same keys; env_monolith.py:22-23 ctor). */
@@ -164,6 +167,9 @@ int mse_rollout(mse_env *env, int32_t k_steps, uint64_t policy_seed, const int32
 /* Samples one masked-uniform action per env from the CURRENT state (same policy stream as
  * mse_rollout); action_out i32[N]. */
 int mse_sample_actions(mse_env *env, uint64_t policy_seed, int32_t *action_out, void *stream);
+
+/* The reference's rule-based action per env for the CURRENT state (env_monolith.py:166-184). */
+int mse_rule_actions(mse_env *env, int32_t *action_out, void *stream);
 
 /* State export / import in a fixed record layout (tests, checkpoint/resume, dashboard trace):
  *   ints  i64[N, MSE_SNAP_INTS]  (column map: MSE_SNAP_* below)

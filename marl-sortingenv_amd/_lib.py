@@ -7,13 +7,13 @@ import os
 from .build import LIB_PATH
 
 MSE_ENV_SORT, MSE_ENV_PRESS, MSE_ENV_MONO = 1, 2, 3
-MSE_STEP_UNMASKED, MSE_STEP_CHECK_OVERFLOW = 1, 2
+MSE_STEP_UNMASKED, MSE_STEP_CHECK_OVERFLOW, MSE_ROLLOUT_RULE_BASED = 1, 2, 4
 MSE_SNAP_INTS = 71
 
 EXPORTS = [
     "mse_version", "mse_last_error", "mse_status_string", "mse_config_default", "mse_create",
     "mse_create_indexed", "mse_destroy", "mse_num_envs", "mse_obs_dim", "mse_num_actions", "mse_reset",
-    "mse_step", "mse_action_masks", "mse_rollout", "mse_sample_actions", "mse_get_state", "mse_set_state",
+    "mse_step", "mse_action_masks", "mse_rollout", "mse_sample_actions", "mse_rule_actions", "mse_get_state", "mse_set_state",
     "mse_error_count", "mse_algorithmic_bytes_per_step",
 ]
 
@@ -83,6 +83,7 @@ def load_library() -> C.CDLL:
     L.mse_action_masks.argtypes = [vp, vp, vp]
     L.mse_rollout.argtypes = [vp, i32, u64, vp, u32, vp, vp, vp, vp, vp, vp]
     L.mse_sample_actions.argtypes = [vp, u64, vp, vp]
+    L.mse_rule_actions.argtypes = [vp, vp, vp]
     L.mse_get_state.argtypes = [vp, vp, vp, vp, vp]
     L.mse_set_state.argtypes = [vp, vp, vp, vp, vp]
     L.mse_error_count.argtypes = [vp, C.POINTER(u64)]

@@ -13,7 +13,8 @@ from typing import Optional
 import torch
 
 from . import _lib
-from ._lib import MSE_SNAP_INTS, MSE_STEP_CHECK_OVERFLOW, MSE_STEP_UNMASKED, check, load_library
+from ._lib import (MSE_ROLLOUT_RULE_BASED, MSE_SNAP_INTS, MSE_STEP_CHECK_OVERFLOW, MSE_STEP_UNMASKED, check,
+                   load_library)
 from .config import NUM_ACTIONS, OBS_DIM, SortingEnvConfig
 
 
@@ -129,6 +130,13 @@ class BatchedSortingEnv:
             check(self.L.mse_sample_actions(self._h, int(policy_seed), _ptr(out), self._stream()))
         return out
 
+    def rule_actions(self) -> torch.Tensor:
+        """The reference's rule-based policy (mode='rule_based') evaluated on the device."""
+        out = torch.empty((self.num_envs,), dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            check(self.L.mse_rule_actions(self._h, _ptr(out), self._stream()))
+        return out
+
     def alloc_rollout(self, k_steps: int, obs=True, mask=True, actions=True, reward=True, done=True):
         n, dev, K = self.num_envs, self.device, int(k_steps)
         return {
@@ -141,13 +149,18 @@ class BatchedSortingEnv:
 
     def rollout(self, k_steps: int, policy_seed: int = 2024, buffers: Optional[dict] = None,
                 sort_mode: Optional[torch.Tensor] = None, use_action_masking: bool = True,
-                check_overflow: bool = False) -> dict:
-        """K fused steps under the on-device masked-uniform random policy (one kernel launch)."""
+                check_overflow: bool = False, policy: str = "random") -> dict:
+        """K fused steps in one kernel launch under an on-device policy: "random" (masked-uniform) or
+        "rule_based" (the reference's mode='rule_based')."""
         if buffers is None:
             buffers = self.alloc_rollout(k_steps)
         if sort_mode is not None:
             sort_mode = sort_mode.to(device=self.device, dtype=torch.int32).contiguous()
         flags = (0 if use_action_masking else MSE_STEP_UNMASKED) | (MSE_STEP_CHECK_OVERFLOW if check_overflow else 0)
+        if policy == "rule_based":
+            flags |= MSE_ROLLOUT_RULE_BASED
+        elif policy != "random":
+            raise ValueError("policy must be 'random' or 'rule_based'")
         with torch.cuda.device(self.device):
             check(self.L.mse_rollout(self._h, int(k_steps), int(policy_seed), _ptr(sort_mode), flags,
                                      _ptr(buffers.get("actions")), _ptr(buffers.get("obs")),

@@ -427,6 +427,30 @@ __device__ __forceinline__ uint32_t action_mask_bits(const Env &e, const Params 
     return KIND == 2 ? m : (m | (m << 11));
 }
 
+// The reference's rule-based policy (env_monolith.py:166-184): sorting_rules() on the belt as it will be after
+// this step's flow (env_super.py:469-482) and check_container_level() (env_super.py:689-720): the first free
+// press takes the fullest non-empty container (strict >, order A..E).  `rule_mode_next` = sorting_rules() of
+// the batch now in the input stage (it is on the belt when the step decides).
+template <int KIND>
+__device__ __forceinline__ int rule_based_action(const Env &e, int rule_mode_next)
+{
+    if (KIND == 1) return rule_mode_next;
+    int press = 0; // 1 | 2, 0 = none free
+    if (e.timer[0] == 0) press = 1;
+    else if (e.timer[1] == 0) press = 2;
+    int best_idx = -1, best_level = 0;
+#pragma unroll
+    for (int m = 0; m < 5; ++m) {
+        const int lvl = m < 4 ? e.ct[m] + e.cf[m] : e.ce;
+        if (lvl > best_level) {
+            best_level = lvl;
+            best_idx = m;
+        }
+    }
+    const int press_action = (press != 0 && best_idx >= 0) ? (press - 1) * 5 + best_idx + 1 : 0;
+    return KIND == 2 ? press_action : rule_mode_next * 11 + press_action;
+}
+
 // press action a in 1..10 -> (press index 0|1, material 0..4)  (env_super.py:804-809)
 __device__ __forceinline__ void decode_press_action(int a, int &press, int &mat)
 {

@@ -126,6 +126,26 @@ __device__ __forceinline__ void auto_reset_env(Env &e, const Params &P, const Ta
     for (int m = 0; m < 4; ++m) k[m] = 101; // empty containers
 }
 
+// action for the next step: the on-device masked-uniform policy (env_monolith.py:152-158 with masking) or,
+// with MSE_ROLLOUT_RULE_BASED, the reference's rule-based policy
+template <int KIND>
+__device__ __forceinline__ int policy_action(const Env &e, const Params &P, const Tables &tb, uint32_t flags,
+                                             uint64_t policy_seed, uint64_t env_index, uint64_t t)
+{
+    if (flags & MSE_ROLLOUT_RULE_BASED) {
+        // stage id of the batch that will be on the belt: what update_environment moves from the input stage
+        const int next_belt = e.st_in;
+        return rule_based_action<KIND>(e, (int)tb.pat[next_belt * kPatStride + 2]);
+    }
+    const uint32_t cur = action_mask_bits<KIND>(e, P);
+    const uint32_t cnt = (uint32_t)__popc(cur);
+    uint32_t rr = policy_u32(policy_seed, env_index, t);
+#ifdef MSE_ABL_NOHASH
+    rr = ((uint32_t)env_index * 2654435761u) ^ ((uint32_t)t * 0x9E3779B9u);
+#endif
+    return select_kth_bit(cur, (int)(((uint64_t)rr * cnt) >> 32));
+}
+
 // ==========================================================================================
 // kernels
 // ==========================================================================================
@@ -230,16 +250,7 @@ __global__ __launch_bounds__(kBlock) void k_rollout(Params P, uint4 *__restrict_
         uint32_t mbits = 0;
         const long long srow = (long long)s * P.n + row0;
         if (live) {
-            // masked-uniform policy on the current state (env_monolith.py:152-158 with masking)
-            uint32_t cur = action_mask_bits<KIND>(e, P);
-            uint32_t cnt = (uint32_t)__popc(cur);
-#ifdef MSE_ABL_NOHASH
-            uint32_t rr = ((uint32_t)i * 2654435761u) ^ ((uint32_t)s * 0x9E3779B9u);
-            rr ^= rr >> 15;
-#else
-            uint32_t rr = policy_u32(policy_seed, (uint64_t)(P.index_offset + i), policy_t0 + (uint64_t)s);
-#endif
-            int a = select_kth_bit(cur, (int)(((uint64_t)rr * cnt) >> 32));
+            int a = policy_action<KIND>(e, P, tb, flags, policy_seed, (uint64_t)(P.index_offset + i), policy_t0 + (uint64_t)s);
 #ifdef MSE_ABL_NOPOLICY
             a = (int)(s & 1) * 11;
 #endif
@@ -343,11 +354,8 @@ __global__ __launch_bounds__(kPoThreads) void k_rollout_po(Params P, uint4 *__re
             // padding lanes (i >= n) hold no env: an all-zero PCG64 never leaves zero and would spin forever in
             // the Lemire rejection loop, so they only keep the barrier count
             if (live) {
-                // masked-uniform policy on the current state (env_monolith.py:152-158 with masking)
-                const uint32_t cur = action_mask_bits<KIND>(e, P);
-                const uint32_t cnt = (uint32_t)__popc(cur);
-                const uint32_t rr = policy_u32(policy_seed, (uint64_t)(P.index_offset + i), policy_t0 + (uint64_t)s);
-                const int a = select_kth_bit(cur, (int)(((uint64_t)rr * cnt) >> 32));
+                const int a = policy_action<KIND>(e, P, tb, flags, policy_seed, (uint64_t)(P.index_offset + i),
+                                                  policy_t0 + (uint64_t)s);
                 Snap sn;
                 env_dynamics<KIND, NOISE, LITERAL>(e, P, tb, a, sm, flags, bales, sn);
                 if (__builtin_expect(sn.done != 0, 0)) { // all envs of a batch finish together: rare, wave-uniform
@@ -505,17 +513,16 @@ __global__ __launch_bounds__(kBlock) void k_masks(Params P, const uint4 *__restr
 }
 
 template <int KIND>
-__global__ __launch_bounds__(kBlock) void k_sample(Params P, const uint4 *__restrict__ planes, uint64_t policy_seed,
-                                                   uint64_t policy_t, int *__restrict__ action_out)
+__global__ __launch_bounds__(kBlock) void k_sample(Params P, const uint4 *__restrict__ planes,
+                                                   const uint32_t *__restrict__ table_image, uint32_t flags,
+                                                   uint64_t policy_seed, uint64_t policy_t, int *__restrict__ action_out)
 {
     const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
     if (i >= P.n) return;
+    const Tables tb = tables_at(table_image, P);
     Env e;
     load_env<KIND, false>(e, planes, P, i);
-    uint32_t cur = action_mask_bits<KIND>(e, P);
-    uint32_t cnt = (uint32_t)__popc(cur);
-    uint32_t rr = policy_u32(policy_seed, (uint64_t)(P.index_offset + i), policy_t);
-    action_out[i] = select_kth_bit(cur, (int)(((uint64_t)rr * cnt) >> 32));
+    action_out[i] = policy_action<KIND>(e, P, tb, flags, policy_seed, (uint64_t)(P.index_offset + i), policy_t);
 }
 
 // snapshot record <-> planes (column map: include/mse.h MSE_SNAP_*, shared with oracle/oracle.py SNAP)
@@ -1109,7 +1116,8 @@ int mse_rollout(mse_env *h, int32_t k_steps, uint64_t policy_seed, const int32_t
     if (!h->seeded) return fail(MSE_ERR_NOT_RESET, "mse_rollout before mse_reset(seeds)");
     if (k_steps < 1) return fail(MSE_ERR_INVALID_ARGUMENT, "k_steps must be >= 1");
     if (!h->P.auto_reset) return fail(MSE_ERR_INVALID_ARGUMENT, "mse_rollout needs auto_reset=1");
-    if (flags & ~(MSE_STEP_UNMASKED | MSE_STEP_CHECK_OVERFLOW)) return fail(MSE_ERR_INVALID_ARGUMENT, "unknown step flag");
+    if (flags & ~(MSE_STEP_UNMASKED | MSE_STEP_CHECK_OVERFLOW | MSE_ROLLOUT_RULE_BASED))
+        return fail(MSE_ERR_INVALID_ARGUMENT, "unknown rollout flag");
     hipStream_t s = static_cast<hipStream_t>(stream);
     switch (h->P.env_kind) {
     case 1: launch_rollout<1>(h, s, k_steps, policy_seed, sort_mode, flags, actions_out, obs_out, reward_out, done_out, mask_out); break;
@@ -1121,18 +1129,28 @@ int mse_rollout(mse_env *h, int32_t k_steps, uint64_t policy_seed, const int32_t
     return MSE_OK;
 }
 
-int mse_sample_actions(mse_env *h, uint64_t policy_seed, int32_t *action_out, void *stream)
+static int sample_actions_impl(mse_env *h, uint32_t pflags, uint64_t policy_seed, int32_t *action_out, void *stream)
 {
     if (!h || !action_out) return fail(MSE_ERR_INVALID_ARGUMENT, "env/action_out is NULL");
-    if (!h->seeded) return fail(MSE_ERR_NOT_RESET, "mse_sample_actions before mse_reset(seeds)");
+    if (!h->seeded) return fail(MSE_ERR_NOT_RESET, "policy sampling before mse_reset(seeds)");
     hipStream_t s = static_cast<hipStream_t>(stream);
     switch (h->P.env_kind) {
-    case 1: hipLaunchKernelGGL(k_sample<1>, grid_of(h), dim3(kBlock), 0, s, h->P, h->planes, policy_seed, h->policy_t, action_out); break;
-    case 2: hipLaunchKernelGGL(k_sample<2>, grid_of(h), dim3(kBlock), 0, s, h->P, h->planes, policy_seed, h->policy_t, action_out); break;
-    default: hipLaunchKernelGGL(k_sample<3>, grid_of(h), dim3(kBlock), 0, s, h->P, h->planes, policy_seed, h->policy_t, action_out); break;
+    case 1: hipLaunchKernelGGL(k_sample<1>, grid_of(h), dim3(kBlock), 0, s, h->P, h->planes, h->tables, pflags, policy_seed, h->policy_t, action_out); break;
+    case 2: hipLaunchKernelGGL(k_sample<2>, grid_of(h), dim3(kBlock), 0, s, h->P, h->planes, h->tables, pflags, policy_seed, h->policy_t, action_out); break;
+    default: hipLaunchKernelGGL(k_sample<3>, grid_of(h), dim3(kBlock), 0, s, h->P, h->planes, h->tables, pflags, policy_seed, h->policy_t, action_out); break;
     }
     MSE_CHECK_LAUNCH();
     return MSE_OK;
+}
+
+int mse_sample_actions(mse_env *h, uint64_t policy_seed, int32_t *action_out, void *stream)
+{
+    return sample_actions_impl(h, 0u, policy_seed, action_out, stream);
+}
+
+int mse_rule_actions(mse_env *h, int32_t *action_out, void *stream)
+{
+    return sample_actions_impl(h, MSE_ROLLOUT_RULE_BASED, 0, action_out, stream);
 }
 
 int mse_action_masks(mse_env *h, uint8_t *mask_out, void *stream)

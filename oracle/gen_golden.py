@@ -170,5 +170,33 @@ def main():
     print(f"total {total/1024:.1f} KiB")
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and "--rule-based" not in sys.argv:
     main()
+
+
+def gen_rule_based(seeds=range(1, 11), steps=200):
+    """Env_3_Monolith.step(mode='rule_based') (env_monolith.py:166-184): the reference's own rule policy
+    (sorting_rules + check_container_level) for the paper's benchmark seeds; actions and rewards per step."""
+    cls = ref_harness.load()["mono"]
+    acts, rews = [], []
+    for s in seeds:
+        env = cls(max_steps=steps, seed=s, noise_sorting=0.0, balesize=200)
+        env.reset(seed=s)
+        a_row, r_row = [], []
+        for _ in range(steps):
+            obs, r, term, trunc, info = env.step(action=None, mode="rule_based", use_action_masking=True)
+            a_row.append(int(info["action"]))
+            r_row.append(float(r))
+        assert term
+        acts.append(a_row)
+        rews.append(r_row)
+    out = dict(seeds=np.array(list(seeds), dtype=np.int64), actions=np.array(acts, dtype=np.int32),
+               rewards=np.array(rews, dtype=np.float64))
+    path = os.path.join(OUT_DIR, "rule_based_mono_n0_seeds1_10.npz")
+    np.savez_compressed(path, **out)
+    cum = out["rewards"].sum(1)
+    print(f"rule_based: cumulative reward {cum.mean():.2f} +- {cum.std():.2f} over seeds {list(seeds)} -> {path}")
+
+
+if __name__ == "__main__" and "--rule-based" in sys.argv:
+    gen_rule_based()

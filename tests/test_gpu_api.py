@@ -130,3 +130,26 @@ def test_c_abi_error_behaviour():
     with pytest.raises(MseError) as ei:
         M.BatchedSortingEnv(kind="mono", num_envs=4, config=cfg)
     assert ei.value.status == -2
+
+
+def test_rule_based_policy_matches_reference_benchmark():
+    """mode='rule_based' (env_monolith.py:166-184) as a device policy: actions and rewards of the reference's
+    own rule-based run for the paper's benchmark seeds 1..10 (fixture from the imported reference;
+    cumulative reward 44.18 +- 1.38, utils/benchmark_plot_summary.py:14 reports 44.03 +- 1.10)."""
+    import torch
+    import marl_sortingenv_amd as M
+
+    z = np.load(os.path.join(replay.GOLDEN_DIR, "rule_based_mono_n0_seeds1_10.npz"))
+    seeds, T = z["seeds"], z["actions"].shape[1]
+    for pipeline in (1, 2):
+        env = M.BatchedSortingEnv(kind="mono", num_envs=len(seeds), seeds=torch.as_tensor(seeds), max_steps=T,
+                                  noise_sorting=0.0, balesize=200, rollout_pipeline=pipeline)
+        first = env.rule_actions().cpu().numpy()
+        assert np.array_equal(first, z["actions"][:, 0])
+        buf = env.rollout(T, policy="rule_based")
+        assert np.array_equal(buf["actions"].cpu().numpy().T, z["actions"])
+        rew = buf["reward"].cpu().numpy().T.astype(np.float64)
+        assert np.max(np.abs(rew - z["rewards"])) <= 1e-6
+        cum = rew.sum(1)
+        assert abs(cum.mean() - 44.18) < 0.01 and abs(cum.std() - 1.38) < 0.01
+        assert bool(buf["done"][-1].all()) and int(buf["done"][:-1].sum()) == 0

@@ -61,6 +61,21 @@ def cpu_baseline(kind: str, max_steps: int, noise: float, balesize: int, budget_
     }
 
 
+def measured_traffic(args, n, chunk):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/r01/traffic.json: FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate --pmc runs); only quoted for the
+    exact workload it was collected on, else null."""
+    path = os.path.join(ROOT, "profiles", "r01", "traffic.json")
+    try:
+        with open(path) as f:
+            t = json.load(f)
+    except OSError:
+        return None
+    if (args.kind, n, chunk, args.noise, args.mode, args.no_outputs) == ("mono", 65536, 16, 0.0, "rollout", False):
+        return t.get("hbm_bytes_per_launch")
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -72,6 +87,8 @@ def main():
     ap.add_argument("--noise", type=float, default=0.0)
     ap.add_argument("--max-steps", type=int, default=200)
     ap.add_argument("--no-outputs", action="store_true", help="diagnostic only: skip obs/mask writes (INVALID as a result)")
+    ap.add_argument("--mode", default="rollout", choices=["rollout", "step"],
+                    help="rollout: fused mse_rollout launches (headline); step: mse_sample_actions + mse_step per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
     args = ap.parse_args()
@@ -102,6 +119,11 @@ def main():
 
     def run(n_steps, events=None):
         done = 0
+        if args.mode == "step":
+            for _ in range(n_steps):
+                act = env.sample_actions(policy_seed=2024)
+                env.step(act)
+            return
         while done < n_steps:
             k = min(chunk, n_steps - done)
             if events is not None:
@@ -164,8 +186,8 @@ def main():
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
-                "kernel": "k_rollout", "launch_ms": per_launch_ms,
+                "frac": achieved / HBM_PEAK_GBPS, "traffic": measured_traffic(args, n, chunk),
+                "kernel": "k_rollout_po" if n <= 131072 else "k_rollout", "launch_ms": per_launch_ms,
                 "algorithmic_bytes_per_env_step": bytes_per_step, "env_steps_per_launch": n * chunk,
             },
         }

@@ -129,7 +129,7 @@ __device__ __forceinline__ void auto_reset_env(Env &e, const Params &P, const Ta
 // action for the next step: the on-device masked-uniform policy (env_monolith.py:152-158 with masking) or,
 // with MSE_ROLLOUT_RULE_BASED, the reference's rule-based policy
 template <int KIND>
-__device__ __forceinline__ int policy_action(const Env &e, const Params &P, const Tables &tb, uint32_t flags,
+__device__ __forceinline__ int policy_action(const Env &e, uint32_t cur, const Tables &tb, uint32_t flags,
                                              uint64_t policy_seed, uint64_t env_index, uint64_t t)
 {
     if (flags & MSE_ROLLOUT_RULE_BASED) {
@@ -137,8 +137,7 @@ __device__ __forceinline__ int policy_action(const Env &e, const Params &P, cons
         const int next_belt = e.st_in;
         return rule_based_action<KIND>(e, (int)tb.pat[next_belt * kPatStride + 2]);
     }
-    const uint32_t cur = action_mask_bits<KIND>(e, P);
-    const uint32_t cnt = (uint32_t)__popc(cur);
+    const uint32_t cnt = (uint32_t)__popc(cur); // cur = action_masks() of the current state
     uint32_t rr = policy_u32(policy_seed, env_index, t);
 #ifdef MSE_ABL_NOHASH
     rr = ((uint32_t)env_index * 2654435761u) ^ ((uint32_t)t * 0x9E3779B9u);
@@ -163,8 +162,6 @@ __global__ __launch_bounds__(kBlock) void k_step(Params P, uint4 *__restrict__ p
     uint8_t *lds = reinterpret_cast<uint8_t *>(mse_dyn_lds);
     uint32_t *ltab = reinterpret_cast<uint32_t *>(lds + LdsLayout<KIND>::table_offset_step);
     const int tid = threadIdx.x;
-    load_tables_to_lds(ltab, table_image, P.table_words, tid);
-    const Tables tb = tables_at(ltab, P);
     const long long row0 = (long long)blockIdx.x * kBlock;
     const long long i = row0 + tid;
     const bool live = i < P.n;
@@ -174,15 +171,20 @@ __global__ __launch_bounds__(kBlock) void k_step(Params P, uint4 *__restrict__ p
 #pragma unroll
     for (int j = 0; j < D; ++j) o[j] = 0.0f;
 
+    // a single-step launch is mostly memory latency: issue the state and action loads first, fill the LDS
+    // tables while they fly (the padded planes make the state load safe for every lane)
+    Env e;
+    load_env<KIND, NOISE>(e, planes, P, i);
+    int a = live ? action[i] : 0;
+    int sm = (KIND == 2 && sort_mode != nullptr && live) ? sort_mode[i] : -1;
+    load_tables_to_lds(ltab, table_image, P.table_words, tid);
+    const Tables tb = tables_at(ltab, P);
+
     if (live) {
-        Env e;
-        load_env<KIND, NOISE>(e, planes, P, i);
-        int a = action[i];
         if (a < 0 || a >= A) {
             atomicAdd(err_count, 1ull);
             a = 0;
         }
-        int sm = (KIND == 2 && sort_mode != nullptr) ? sort_mode[i] : -1;
         int k[4];
         StepResult r = env_step<KIND, NOISE, LITERAL>(e, P, tb, a, sm, flags, bales, k, o);
         if (r.done && P.auto_reset) {
@@ -245,12 +247,13 @@ __global__ __launch_bounds__(kBlock) void k_rollout(Params P, uint4 *__restrict_
     float o[D];
 #pragma unroll
     for (int j = 0; j < D; ++j) o[j] = 0.0f;
+    uint32_t cur_mask = live ? action_mask_bits<KIND>(e, P) : 1u;
 
     for (int s = 0; s < k_steps; ++s) {
         uint32_t mbits = 0;
         const long long srow = (long long)s * P.n + row0;
         if (live) {
-            int a = policy_action<KIND>(e, P, tb, flags, policy_seed, (uint64_t)(P.index_offset + i), policy_t0 + (uint64_t)s);
+            int a = policy_action<KIND>(e, cur_mask, tb, flags, policy_seed, (uint64_t)(P.index_offset + i), policy_t0 + (uint64_t)s);
 #ifdef MSE_ABL_NOPOLICY
             a = (int)(s & 1) * 11;
 #endif
@@ -263,6 +266,7 @@ __global__ __launch_bounds__(kBlock) void k_rollout(Params P, uint4 *__restrict_
 #ifndef MSE_ABL_NOMASK
             mbits = action_mask_bits<KIND>(e, P);
 #endif
+            cur_mask = mbits; // what the next step's policy sees
             if (actions_out != nullptr) actions_out[(long long)s * P.n + i] = a;
             if (reward_out != nullptr) reward_out[(long long)s * P.n + i] = (float)r.reward;
             if (done_out != nullptr) done_out[(long long)s * P.n + i] = (uint8_t)r.done;
@@ -350,11 +354,12 @@ __global__ __launch_bounds__(kPoThreads) void k_rollout_po(Params P, uint4 *__re
             if (KIND == 2 && sort_mode != nullptr) sm = sort_mode[i];
         }
         __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): no load is outstanding inside the step loop
+        uint32_t cur_mask = live ? action_mask_bits<KIND>(e, P) : 1u;
         for (int s = 0; s < k_steps; ++s) {
             // padding lanes (i >= n) hold no env: an all-zero PCG64 never leaves zero and would spin forever in
             // the Lemire rejection loop, so they only keep the barrier count
             if (live) {
-                const int a = policy_action<KIND>(e, P, tb, flags, policy_seed, (uint64_t)(P.index_offset + i),
+                const int a = policy_action<KIND>(e, cur_mask, tb, flags, policy_seed, (uint64_t)(P.index_offset + i),
                                                   policy_t0 + (uint64_t)s);
                 Snap sn;
                 env_dynamics<KIND, NOISE, LITERAL>(e, P, tb, a, sm, flags, bales, sn);
@@ -363,6 +368,7 @@ __global__ __launch_bounds__(kPoThreads) void k_rollout_po(Params P, uint4 *__re
                     auto_reset_env(e, P, tb, bales, kdummy);
                 }
                 const uint32_t mbits = action_mask_bits<KIND>(e, P); // what the next action sees (after auto-reset)
+                cur_mask = mbits;
                 uint32_t *w = lsnap + (s & 1) * SW * kPoEnvs + el;
 #pragma unroll
                 for (int m = 0; m < 4; ++m) {
@@ -522,7 +528,8 @@ __global__ __launch_bounds__(kBlock) void k_sample(Params P, const uint4 *__rest
     const Tables tb = tables_at(table_image, P);
     Env e;
     load_env<KIND, false>(e, planes, P, i);
-    action_out[i] = policy_action<KIND>(e, P, tb, flags, policy_seed, (uint64_t)(P.index_offset + i), policy_t);
+    action_out[i] = policy_action<KIND>(e, action_mask_bits<KIND>(e, P), tb, flags, policy_seed,
+                                        (uint64_t)(P.index_offset + i), policy_t);
 }
 
 // snapshot record <-> planes (column map: include/mse.h MSE_SNAP_*, shared with oracle/oracle.py SNAP)

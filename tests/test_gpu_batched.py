@@ -188,3 +188,98 @@ def test_pipelined_rollout_equals_single_role_rollout(kind, noise):
             assert torch.equal(ra[key], rb[key]), (key, chunk)
     for x, y in zip(a.get_state(), b.get_state()):
         assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_state_export_import_resumes_bit_exactly(kind):
+    """mse_get_state / mse_set_state as checkpoint/resume: a second handle restored from a mid-run
+    snapshot continues exactly like the original (buffers and final state)."""
+    import torch
+
+    n = 777
+    kw = dict(base_seed=50, max_steps=35, noise_sorting=0.05, balesize=200)
+    a = _mk(kind, n, **kw)
+    a.rollout(23, policy_seed=4)
+    snap = [t.clone() for t in a.get_state()]
+    b = _mk(kind, n, base_seed=999, max_steps=35, noise_sorting=0.05, balesize=200)  # different streams on purpose
+    b.set_state(*snap)
+    # the policy stream is keyed by the handle's step counter: compare with explicit actions
+    for _ in range(30):
+        act = a.sample_actions(policy_seed=8)
+        oa = [t.clone() for t in a.step(act, want_reward64=True)]
+        ob = b.step(act, want_reward64=True)
+        for x, y in zip(oa, ob):
+            assert torch.equal(x, y)
+    for x, y in zip(a.get_state(), b.get_state()):
+        assert torch.equal(x, y)
+    assert b.error_count() == 0
+
+
+def test_partial_reset_with_which_mask():
+    """mse_reset(which): only the selected envs restart (seeded or unseeded); the others keep stepping."""
+    import torch
+
+    n = 300
+    env = _mk("mono", n, base_seed=7, max_steps=500, noise_sorting=0.0, auto_reset=False)
+    oracles = [OracleEnv(kind="mono", max_steps=500, seed=7 + i, noise_sorting=0.0) for i in range(n)]
+    for i, o in enumerate(oracles):
+        o.reset(7 + i)
+
+    def step_all(t):
+        act = env.sample_actions(policy_seed=t)
+        obs, rew, done, mask = env.step(act)
+        a = act.cpu().numpy()
+        ob = obs.cpu().numpy()
+        for i, o in enumerate(oracles):
+            eo, er, et = o.step(int(a[i]))
+            assert np.array_equal(ob[i].view(np.uint32), eo.view(np.uint32)), (t, i)
+
+    for t in range(25):
+        step_all(t)
+    which = (torch.arange(n) % 3 == 0).to(torch.uint8)
+    new_seeds = torch.arange(n, dtype=torch.int64) + 1000
+    obs, mask = env.reset(seeds=new_seeds, which=which)               # seeded, partial
+    for i, o in enumerate(oracles):
+        exp = o.reset(1000 + i) if which[i] else o.obs()
+        assert np.array_equal(obs[i].cpu().numpy().view(np.uint32), exp.view(np.uint32)), i
+        assert np.array_equal(mask[i].cpu().numpy(), o.action_masks())
+    for t in range(25, 40):
+        step_all(t)
+    which2 = (torch.arange(n) % 5 == 1).to(torch.uint8)
+    obs, mask = env.reset(seeds=None, which=which2)                   # unseeded (streams continue), partial
+    for i, o in enumerate(oracles):
+        exp = o.reset(None) if which2[i] else o.obs()
+        assert np.array_equal(obs[i].cpu().numpy().view(np.uint32), exp.view(np.uint32)), i
+    for t in range(40, 70):
+        step_all(t)
+    _compare_state(env, oracles)
+
+
+def test_extreme_sizes():
+    """N = 1 and N = 2 097 152 (BASELINE.json config 5's global size on one GPU): conservation and determinism."""
+    import torch
+
+    one = _mk("mono", 1, base_seed=3, max_steps=200, noise_sorting=0.0)
+    o = OracleEnv(kind="mono", max_steps=200, seed=3, noise_sorting=0.0)
+    o.reset(3)
+    buf = one.rollout(64, policy_seed=1)
+    for k in range(64):
+        eo, er, et = o.step(int(buf["actions"][k, 0]))
+        assert np.array_equal(buf["obs"][k, 0].cpu().numpy().view(np.uint32), eo.view(np.uint32))
+    big_n = 2097152
+    big = _mk("mono", big_n, base_seed=0, max_steps=200, noise_sorting=0.0)
+    bufs = big.alloc_rollout(4)
+    for _ in range(3):
+        big.rollout(4, policy_seed=2024, buffers=bufs)
+    ints, _, _ = big.get_state()
+    S = SNAP
+    in_system = (ints[:, S["input"]].sum(1) + ints[:, S["belt"]].sum(1) + ints[:, S["cont_true"]].sum(1)
+                 + ints[:, S["cont_false"]].sum(1) + ints[:, S["cont_e"]].sum(1) + ints[:, S["press_n"]].sum(1)
+                 + ints[:, S["bale_sum"]].sum(1))
+    assert bool((in_system == 100 * 12).all())
+    # the first 65 536 envs of the big batch equal a 65 536-env batch (results do not depend on N)
+    small = _mk("mono", 65536, base_seed=0, max_steps=200, noise_sorting=0.0)
+    sb = small.alloc_rollout(4)
+    for _ in range(3):
+        small.rollout(4, policy_seed=2024, buffers=sb)
+    assert torch.equal(bufs["obs"][:, :65536], sb["obs"]) and torch.equal(bufs["reward"][:, :65536], sb["reward"])

@@ -75,7 +75,7 @@ struct Params {
     int sev_negative, mild_negative; // overflow_penalty_severe / _mild < 0 (then that bracket returns early)
     int k_thr[4];           // hundredths of python round(quality_threshold, 2): purity of an empty container
     // offsets (in 4-byte words) into the table image; see build_tables
-    int off_lvl, off_pdiff, off_timer0, off_timer1, off_tanh, off_eff, off_pat, off_acc, off_bonus, off_ptime, off_cst, table_words;
+    int off_lvl, off_pdiff, off_timer0, off_timer1, off_tanh, off_eff, off_pat, off_acc, off_bonus, off_ptime, off_cst, off_jump, table_words;
 };
 
 // ------------------------------------------------------------------------------------------
@@ -535,6 +535,75 @@ __device__ __forceinline__ int choice4_literal(uint32_t C, uint64_t r64)
     return (n0 <= u ? 1 : 0) + (n1 <= u ? 1 : 0) + (n2 <= u ? 1 : 0) + (n3 <= u ? 1 : 0);
 }
 
+// ------------------------------------------------------------------------------------------
+// where sort_material's PCG64 outputs come from
+// ------------------------------------------------------------------------------------------
+// 128-bit LCG jump-ahead: n steps of s' = M s + inc are s_n = A_n s + G_n inc with A_n = M^n and
+// G_n = 1 + M + ... + M^(n-1); the host tabulates (A, G) for n = 2^j (build_tables) and a jump multiplies
+// the set bits of n together.  Used only off the hot path (final stream state of a ring rollout, and the
+// full 64-bit output of a draw that needs the literal cdf).
+constexpr int kJumpBits = 24;
+__device__ __forceinline__ void mul128(uint64_t a_lo, uint64_t a_hi, uint64_t b_lo, uint64_t b_hi, uint64_t &r_lo,
+                                       uint64_t &r_hi)
+{
+    r_lo = a_lo * b_lo;
+    r_hi = __umul64hi(a_lo, b_lo) + a_lo * b_hi + a_hi * b_lo;
+}
+__device__ __forceinline__ void pcg_jump(Pcg &g, uint32_t n, const uint64_t *jump_tab /* [kJumpBits][4] = A_lo A_hi G_lo G_hi */)
+{
+    for (int j = 0; n != 0 && j < kJumpBits; ++j, n >>= 1) {
+        if (n & 1u) {
+            const uint64_t *t = jump_tab + 4 * j;
+            uint64_t x_lo, x_hi, y_lo, y_hi;
+            mul128(t[0], t[1], g.s_lo, g.s_hi, x_lo, x_hi);
+            mul128(t[2], t[3], g.i_lo, g.i_hi, y_lo, y_hi);
+            const uint64_t lo = x_lo + y_lo;
+            g.s_hi = x_hi + y_hi + (lo < x_lo ? 1ull : 0ull);
+            g.s_lo = lo;
+        }
+    }
+}
+
+// the lane advances the env's own generator
+struct RngLocal {
+    Pcg &g;
+    __device__ __forceinline__ void begin_step() {}
+    __device__ __forceinline__ uint32_t next_hi32()
+    {
+        pcg_advance(g);
+        return pcg_output_hi32(g);
+    }
+    __device__ __forceinline__ uint64_t last_full() const { return pcg_output(g); }
+};
+
+// Outputs produced ahead by an RNG wave into an LDS ring of the upper 32 bits (k_rollout_ring).
+// Output #p (p = 0, 1, ...) is the output of the state p+1 steps after `start`.  Layout: 16 chunks of
+// [256 lanes][4 words]; output #p of env slot el sits at ring[((p >> 2) & 15) * 1024 + el * 4 + (p & 3)].
+constexpr int kRingDepth = 64;        // outputs per env
+constexpr int kRingMaxPerStep = 31;   // the producer lags one barrier: two steps' draws must fit in the ring
+struct RngRing {
+    const uint32_t *lane_base; // ring + el * 4
+    const uint64_t *jump_tab;
+    Pcg start;                 // stream state when the launch began (never advanced)
+    uint32_t pos;              // outputs consumed so far = index of the next one
+    uint32_t nxt;              // prefetched output #pos
+    __device__ __forceinline__ uint32_t load(uint32_t p) const { return lane_base[((p >> 2) & 15u) * 1024u + (p & 3u)]; }
+    __device__ __forceinline__ void begin_step() { nxt = load(pos); }
+    __device__ __forceinline__ uint32_t next_hi32()
+    {
+        const uint32_t v = nxt;
+        pos += 1u;
+        nxt = load(pos); // issued a whole decision ahead of its use
+        return v;
+    }
+    __device__ __forceinline__ uint64_t last_full() const
+    {
+        Pcg g = start;
+        pcg_jump(g, pos, jump_tab); // the state whose output was just consumed
+        return pcg_output(g);
+    }
+};
+
 // env_super.py:511-609 sort_material.
 //
 // leftover[4] is carried as the four byte-wise PREFIX SUMS C = {c_0, c_1, c_2, c_3 = T} in one register
@@ -546,8 +615,8 @@ __device__ __forceinline__ int choice4_literal(uint32_t C, uint64_t r64)
 // Byte k of D = (0x80 + v) - c_k keeps bit 7 iff c_k <= v; the chosen bin is the first k with c_k > v and
 // removing one unit there lowers every prefix sum from k on by one: C += (flags >> 7) - 0x01010101.
 // If f is within a wide margin of 0 or 2^32 the literal fp64 path decides instead (DESIGN.md "choice").
-template <bool LITERAL>
-__device__ __forceinline__ void draw_units(Pcg &rng, uint32_t &C, int &rem)
+template <bool LITERAL, class RNG>
+__device__ __forceinline__ void draw_units(RNG &rng, uint32_t &C, int &rem)
 {
 #ifdef MSE_ABL_NODRAW
     rem = 0;
@@ -556,18 +625,18 @@ __device__ __forceinline__ void draw_units(Pcg &rng, uint32_t &C, int &rem)
     // draws with its own false units in the pool (T >= rem) and every draw lowers both T and rem by one.
     while (rem > 0) {
         const uint32_t T = C >> 24;
-        pcg_advance(rng);
+        const uint32_t r_hi = rng.next_hi32();
         uint32_t flags; // bit 7 of byte k set iff bin k is passed over (c_k <= v)
         bool literal = LITERAL;
         if (!LITERAL) {
-            const uint64_t prod = mul64_vv(pcg_output_hi32(rng), T);
+            const uint64_t prod = mul64_vv(r_hi, T);
             const uint32_t f = (uint32_t)prod;
             const uint32_t v = (uint32_t)(prod >> 32);
             flags = ((__umul24(v, 0x010101u) | 0x00808080u) - C) & 0x00808080u; // bytes 0..2 only; v < 128
             literal = (f + 0x200u) < 0x210u; // f < 16 or f >= 2^32 - 512
         }
         if (__builtin_expect(literal, 0)) { // ~1e-7 per draw: keep it out of the loop's straight line
-            const int sel = choice4_literal(C, pcg_output(rng));
+            const int sel = choice4_literal(C, rng.last_full());
             flags = sel == 0 ? 0u : (sel == 1 ? 0x00000080u : (sel == 2 ? 0x00008080u : 0x00808080u));
         }
         C += (flags >> 7) + 0xFEFEFEFFu; // - 0x01010101 on the bins from the chosen one on
@@ -593,26 +662,27 @@ __device__ __forceinline__ void station_split(Env &e, uint32_t &C, const double 
 // Stations are walked in the reference's order.  Stations I and I+1 share one draw loop: a lane whose
 // station I has nothing to redistribute (accuracy 1.0 after the boost) starts station I+1 at once, so a
 // wave runs max(f_I, f_{I+1}) iterations instead of f_I + f_{I+1} when its lanes sit in different modes.
-template <bool LITERAL, int I>
-__device__ __forceinline__ void station_pair(Env &e, uint32_t &C, const double acc_sorter[4])
+template <bool LITERAL, int I, class RNG>
+__device__ __forceinline__ void station_pair(Env &e, RNG &rng, uint32_t &C, const double acc_sorter[4])
 {
     int rem;
     station_split<I>(e, C, acc_sorter, rem);
     const bool early = rem == 0;
     if (early) station_split<I + 1>(e, C, acc_sorter, rem);
-    draw_units<LITERAL>(e.rng, C, rem);
+    draw_units<LITERAL>(rng, C, rem);
     if (!early) {
         station_split<I + 1>(e, C, acc_sorter, rem);
-        draw_units<LITERAL>(e.rng, C, rem);
+        draw_units<LITERAL>(rng, C, rem);
     }
 }
 
-template <bool LITERAL>
-__device__ __forceinline__ void sort_material(Env &e, uint32_t sorting_word, const double acc_sorter[4])
+template <bool LITERAL, class RNG>
+__device__ __forceinline__ void sort_material(Env &e, RNG &rng, uint32_t sorting_word, const double acc_sorter[4])
 {
+    rng.begin_step();
     uint32_t C = sorting_word * 0x01010101u; // prefix sums of current_material_sorting
-    station_pair<LITERAL, 0>(e, C, acc_sorter);
-    station_pair<LITERAL, 2>(e, C, acc_sorter);
+    station_pair<LITERAL, 0>(e, rng, C, acc_sorter);
+    station_pair<LITERAL, 2>(e, rng, C, acc_sorter);
     e.ce += (int)(C >> 24); // env_super.py:579,597
 }
 
@@ -782,6 +852,7 @@ struct Tables {
     // rarely used fp64 constants live here too: as kernel arguments they were re-fetched with s_load inside
     // the step loop (SGPR pressure), each fetch a scalar-cache round trip
     const double *cst;     // [CST_COUNT], see enum Cst
+    const uint64_t *jump;  // [kJumpBits][4] LCG jump-ahead (pcg_jump)
 };
 
 __device__ __forceinline__ Tables tables_at(const uint32_t *base, const Params &P)
@@ -798,6 +869,7 @@ __device__ __forceinline__ Tables tables_at(const uint32_t *base, const Params &
     t.bonus = reinterpret_cast<const double *>(base + P.off_bonus);
     t.press_time = reinterpret_cast<const int *>(base + P.off_ptime);
     t.cst = reinterpret_cast<const double *>(base + P.off_cst);
+    t.jump = reinterpret_cast<const uint64_t *>(base + P.off_jump);
     return t;
 }
 
@@ -956,9 +1028,9 @@ __device__ __forceinline__ PenaltyClass classify_levels(const int lvl[5], const 
 
 // env_1_sort.py:97-154 / env_2_press.py:88-165 / env_monolith.py:109-284 up to (not including) the reward
 // and observation, plus the state side effects of calculate_press_reward and the step counter.
-template <int KIND, bool NOISE, bool LITERAL>
-__device__ __forceinline__ void env_dynamics(Env &e, const Params &P, const Tables &tb, int action, int sort_mode_in,
-                                             uint32_t flags, const BaleRef &bales, Snap &sn)
+template <int KIND, bool NOISE, bool LITERAL, class RNG>
+__device__ __forceinline__ void env_dynamics(Env &e, RNG &rng, const Params &P, const Tables &tb, int action,
+                                             int sort_mode_in, uint32_t flags, const BaleRef &bales, Snap &sn)
 {
     const bool unmasked = (flags & 1u) != 0;
     const bool check_overflow = (flags & 2u) != 0;
@@ -987,7 +1059,7 @@ __device__ __forceinline__ void env_dynamics(Env &e, const Params &P, const Tabl
     double acc_sorter[4];
     update_accuracy<NOISE>(e, tb.cst, tb.acc, sort_mode, acc_sorter);
 #ifndef MSE_ABL_NOSORT
-    sort_material<LITERAL>(e, sorting_word, acc_sorter);
+    sort_material<LITERAL>(e, rng, sorting_word, acc_sorter);
 #endif
 
     if (KIND == 1) {
@@ -1193,7 +1265,8 @@ __device__ __forceinline__ StepResult env_step(Env &e, const Params &P, const Ta
                                                uint32_t flags, const BaleRef &bales, int k[4], float *o)
 {
     Snap sn;
-    env_dynamics<KIND, NOISE, LITERAL>(e, P, tb, action, sort_mode_in, flags, bales, sn);
+    RngLocal rng{e.rng};
+    env_dynamics<KIND, NOISE, LITERAL>(e, rng, P, tb, action, sort_mode_in, flags, bales, sn);
     return env_observe<KIND, NOISE>(sn, P, tb, k, o);
 }
 

@@ -60,7 +60,8 @@ __device__ __forceinline__ void stage_and_store(uint8_t *lds_base, int mask_offs
     const int wave = tid >> 6, lane = tid & 63;
     const int n_valid = min(max(n_valid_block - wave * 64, 0), 64);
     float *lobs = reinterpret_cast<float *>(lds_base) + wave * 64 * D;
-    uint8_t *lmask = lds_base + mask_offset + wave * 64 * A;
+    // mask_offset < 0: the wave's mask tile reuses its own obs tile (callers then stage obs and mask in two calls)
+    uint8_t *lmask = mask_offset < 0 ? reinterpret_cast<uint8_t *>(lobs) : lds_base + mask_offset + wave * 64 * A;
     if (gobs != nullptr) {
 #pragma unroll
         for (int j = 0; j < D; ++j) lobs[lane * D + j] = o[j];
@@ -362,7 +363,8 @@ __global__ __launch_bounds__(kPoThreads) void k_rollout_po(Params P, uint4 *__re
                 const int a = policy_action<KIND>(e, cur_mask, tb, flags, policy_seed, (uint64_t)(P.index_offset + i),
                                                   policy_t0 + (uint64_t)s);
                 Snap sn;
-                env_dynamics<KIND, NOISE, LITERAL>(e, P, tb, a, sm, flags, bales, sn);
+                RngLocal rng{e.rng};
+                env_dynamics<KIND, NOISE, LITERAL>(e, rng, P, tb, a, sm, flags, bales, sn);
                 if (__builtin_expect(sn.done != 0, 0)) { // all envs of a batch finish together: rare, wave-uniform
                     int kdummy[4];
                     auto_reset_env(e, P, tb, bales, kdummy);
@@ -447,6 +449,214 @@ __global__ __launch_bounds__(kPoThreads) void k_rollout_po(Params P, uint4 *__re
             const long long srow = (long long)s * P.n + row0;
             stage_and_store<KIND>(lds, L::obs_bytes, o, mbits, obs_out ? obs_out + srow * D : nullptr,
                                   mask_out ? mask_out + srow * A : nullptr, n_valid_block, tid - kPoEnvs);
+        }
+    }
+}
+
+// ==========================================================================================
+// Ring rollout: dynamics waves + observer waves + RNG waves  (DESIGN.md "Ring rollout")
+//
+// In the pipelined kernel the dynamics wave is the critical path and 60 % of it is sort_material's draws,
+// half of whose instructions are the PCG64 step itself.  The stream does not depend on the env's state, so a
+// third set of waves produces it ahead of time: a 768-thread workgroup serves 256 envs with
+//   waves 0-3  dynamics  (policy, flow, station splits, draw DECISIONS on ring outputs, presses)
+//   waves 4-7  observers (as in k_rollout_po)
+//   waves 8-11 RNG       (advance the env's PCG64 sequentially, write the upper 32 output bits to an LDS ring)
+// and wave w, w+4, w+8 share a SIMD.  Flow control rides on the per-step barrier B_s: before B_s the dynamics
+// lanes publish how many outputs they have consumed (r_s); after it the RNG lanes fill their ring up to
+// r_s + 64.  A step consumes at most kRingMaxPerStep = 31 outputs (host-checked bound on the config), so the
+// outputs of step s+1 (< r_s + 32) were all written before B_s (>= r_{s-1} + 64 >= r_s + 33), and what the RNG
+// lanes overwrite after B_s (ring slots of outputs < r_s) has been consumed.  The env's stream state is only
+// needed again at the end of the launch (start state jumped ahead by the consumed count) and for the 1e-7 draw
+// that wants the literal cdf (full output recomputed by a jump).
+// ==========================================================================================
+constexpr int kRingThreads = 3 * kPoEnvs;
+
+template <int KIND, bool NOISE>
+struct RingLayout {
+    static constexpr int D = Dims<KIND>::D, A = Dims<KIND>::A;
+    static constexpr int snap_words = kSnapWordsBase + (NOISE ? 4 : 0); // accuracy_belt travels as 4 x f32
+    static constexpr int stage_bytes = kPoEnvs * D * 4;                 // obs tile; the mask tile reuses it
+    static constexpr int snap_offset = stage_bytes;
+    static constexpr int snap_bytes = 2 * snap_words * kPoEnvs * 4;
+    static constexpr int bale_offset = snap_offset + snap_bytes;
+    static constexpr int bale_bytes = 5 * kPoEnvs * 16;
+    static constexpr int ring_offset = bale_offset + bale_bytes;
+    static constexpr int ring_bytes = kRingDepth * kPoEnvs * 4;
+    static constexpr int pos_offset = ring_offset + ring_bytes;
+    static constexpr int pos_bytes = kPoEnvs * 4;
+    static constexpr int table_offset = pos_offset + pos_bytes; // multiple of 16
+};
+
+template <int KIND, bool NOISE>
+__global__ __launch_bounds__(kRingThreads) void k_rollout_ring(Params P, uint4 *__restrict__ planes,
+                                                               const uint32_t *__restrict__ table_image, int k_steps,
+                                                               uint64_t policy_seed, uint64_t policy_t0,
+                                                               const int *__restrict__ sort_mode, uint32_t flags,
+                                                               int *__restrict__ actions_out,
+                                                               float *__restrict__ obs_out,
+                                                               float *__restrict__ reward_out,
+                                                               uint8_t *__restrict__ done_out,
+                                                               uint8_t *__restrict__ mask_out)
+{
+    using L = RingLayout<KIND, NOISE>;
+    constexpr int D = L::D, A = L::A, SW = L::snap_words;
+    uint8_t *lds = reinterpret_cast<uint8_t *>(mse_dyn_lds);
+    uint32_t *ltab = reinterpret_cast<uint32_t *>(lds + L::table_offset);
+    uint32_t *lsnap = reinterpret_cast<uint32_t *>(lds + L::snap_offset);
+    uint4 *lbale = reinterpret_cast<uint4 *>(lds + L::bale_offset);
+    uint32_t *lring = reinterpret_cast<uint32_t *>(lds + L::ring_offset);
+    uint32_t *lpos = reinterpret_cast<uint32_t *>(lds + L::pos_offset);
+    const int tid = threadIdx.x;
+    const int role = tid / kPoEnvs;                  // wave-uniform: 0 dynamics, 1 observer, 2 RNG
+    const int el = tid - role * kPoEnvs;             // env slot inside the workgroup (same for the three roles)
+    const long long row0 = (long long)blockIdx.x * kPoEnvs;
+    const long long i = row0 + el;                   // < n_pad always
+    const bool live = i < P.n;
+
+    for (int w = tid; w < P.table_words; w += kRingThreads) ltab[w] = table_image[w];
+    __syncthreads();
+    const Tables tb = tables_at(ltab, P);
+
+    if (role == 2) {
+        // ------------------------------------------------------------------ RNG waves
+        Pcg g;
+        {
+            const uint4 a = planes[PL_RNG_STATE * P.n_pad + i], b = planes[PL_RNG_INC * P.n_pad + i];
+            g.s_lo = (uint64_t)a.x | ((uint64_t)a.y << 32);
+            g.s_hi = (uint64_t)a.z | ((uint64_t)a.w << 32);
+            g.i_lo = (uint64_t)b.x | ((uint64_t)b.y << 32);
+            g.i_hi = (uint64_t)b.z | ((uint64_t)b.w << 32);
+        }
+        uint32_t *base = lring + el * 4;
+        uint32_t w = 0, target = live ? 32u : 0u; // enough for the first step (kRingMaxPerStep < 32)
+        for (int s = -1; s < k_steps; ++s) {
+            while (w < target) { // per-lane trip count: a lane tops its own ring up
+                pcg_advance(g);
+                base[((w >> 2) & 15u) * 1024u + (w & 3u)] = pcg_output_hi32(g);
+                w += 1u;
+            }
+            lds_barrier_all(); // s == -1: B_init (first outputs are in place); else B_s
+            if (s + 1 < k_steps || s == -1) target = live ? lpos[el] + (uint32_t)kRingDepth : 0u;
+            if (s == -1) target = live ? (uint32_t)kRingDepth : 0u; // nothing consumed yet
+        }
+    } else if (role == 0) {
+        // ------------------------------------------------------------------ dynamics waves
+        const BaleRef bales{lbale + el, kPoEnvs};
+        if (P.track_bales) {
+#pragma unroll
+            for (int m = 0; m < 5; ++m) lbale[m * kPoEnvs + el] = planes[(long long)(PL_BALE0 + m) * P.n_pad + i];
+        }
+        Env e;
+        int sm = -1;
+        if (live) {
+            load_env<KIND, NOISE>(e, planes, P, i);
+            if (KIND == 2 && sort_mode != nullptr) sm = sort_mode[i];
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): no load is outstanding inside the step loop
+        RngRing rng;
+        rng.lane_base = lring + el * 4;
+        rng.jump_tab = tb.jump;
+        rng.start = e.rng;
+        rng.pos = 0;
+        rng.nxt = 0;
+        uint32_t cur_mask = live ? action_mask_bits<KIND>(e, P) : 1u;
+        lpos[el] = 0;
+        lds_barrier_all(); // B_init
+        for (int s = 0; s < k_steps; ++s) {
+            if (live) { // padding lanes only keep the barrier count
+                const int a = policy_action<KIND>(e, cur_mask, tb, flags, policy_seed, (uint64_t)(P.index_offset + i),
+                                                  policy_t0 + (uint64_t)s);
+                Snap sn;
+                env_dynamics<KIND, NOISE, false>(e, rng, P, tb, a, sm, flags, bales, sn);
+                if (__builtin_expect(sn.done != 0, 0)) { // all envs of a batch finish together: rare, wave-uniform
+                    int kdummy[4];
+                    auto_reset_env(e, P, tb, bales, kdummy);
+                }
+                const uint32_t mbits = action_mask_bits<KIND>(e, P); // what the next action sees (after auto-reset)
+                cur_mask = mbits;
+                uint32_t *w = lsnap + (s & 1) * SW * kPoEnvs + el;
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    w[m * kPoEnvs] = (uint32_t)sn.ct[m];
+                    w[(4 + m) * kPoEnvs] = (uint32_t)sn.cf[m];
+                }
+                w[8 * kPoEnvs] = (uint32_t)sn.ce;
+                w[9 * kPoEnvs] = (uint32_t)sn.lpa;
+                w[10 * kPoEnvs] = (uint32_t)sn.timer[0] | ((uint32_t)sn.timer[1] << 8) | ((uint32_t)sn.st_belt << 16) |
+                                  ((uint32_t)sn.st_sort << 18) | ((uint32_t)sn.mode << 20) | ((uint32_t)sn.lps << 22) |
+                                  ((uint32_t)sn.done << 23) | ((uint32_t)sn.overflowed << 24);
+                w[11 * kPoEnvs] = (uint32_t)a;
+                w[12 * kPoEnvs] = mbits;
+                if (NOISE) {
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) w[(13 + m) * kPoEnvs] = __float_as_uint((float)sn.acc[m]);
+                }
+                lpos[el] = rng.pos; // r_s for the RNG lane of this env
+            }
+            lds_barrier_all(); // B_s
+        }
+        if (live) {
+            pcg_jump(e.rng, rng.pos, tb.jump); // the stream position after everything this launch consumed
+            store_env<KIND, NOISE>(e, planes, P, i, false);
+        }
+        if (P.track_bales) {
+#pragma unroll
+            for (int m = 0; m < 5; ++m) planes[(long long)(PL_BALE0 + m) * P.n_pad + i] = lbale[m * kPoEnvs + el];
+        }
+    } else {
+        // ------------------------------------------------------------------ observer waves
+        long long rem = P.n - row0;
+        const int n_valid_block = rem >= kPoEnvs ? kPoEnvs : (rem > 0 ? (int)rem : 0);
+        float o[D];
+#pragma unroll
+        for (int j = 0; j < D; ++j) o[j] = 0.0f;
+        lds_barrier_all(); // B_init
+        for (int s = 0; s < k_steps; ++s) {
+            lds_barrier_all(); // B_s: the snapshot of step s is complete
+            const uint32_t *w = lsnap + (s & 1) * SW * kPoEnvs + el;
+            Snap sn;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                sn.ct[m] = (int)w[m * kPoEnvs];
+                sn.cf[m] = (int)w[(4 + m) * kPoEnvs];
+            }
+            sn.ce = (int)w[8 * kPoEnvs];
+            sn.lpa = (int)w[9 * kPoEnvs];
+            const uint32_t pk = w[10 * kPoEnvs];
+            const int a = (int)w[11 * kPoEnvs];
+            const uint32_t mbits = w[12 * kPoEnvs];
+            if (NOISE) {
+#pragma unroll
+                for (int m = 0; m < 4; ++m) sn.acc[m] = (double)__uint_as_float(w[(13 + m) * kPoEnvs]);
+            }
+            sn.timer[0] = (int)(pk & 0xFFu);
+            sn.timer[1] = (int)((pk >> 8) & 0xFFu);
+            sn.st_belt = (int)((pk >> 16) & 3u);
+            sn.st_sort = (int)((pk >> 18) & 3u);
+            sn.mode = (int)((pk >> 20) & 3u);
+            sn.lps = (int)((pk >> 22) & 1u);
+            sn.done = (int)((pk >> 23) & 1u);
+            sn.overflowed = (int)((pk >> 24) & 1u);
+            if (live) { // the snapshot slots of padding lanes are never written
+                int k[4];
+                StepResult r = env_observe<KIND, NOISE>(sn, P, tb, k, o);
+                if (__builtin_expect(sn.done != 0, 0)) { // the step's observation is the one after the auto-reset
+                    Snap rs;
+                    snap_of_reset(rs, tb.cst);
+                    int k2[4];
+                    (void)env_observe<KIND, true>(rs, P, tb, k2, o);
+                }
+                if (actions_out != nullptr) actions_out[(long long)s * P.n + i] = a;
+                if (reward_out != nullptr) reward_out[(long long)s * P.n + i] = (float)r.reward;
+                if (done_out != nullptr) done_out[(long long)s * P.n + i] = (uint8_t)r.done;
+            }
+            const long long srow = (long long)s * P.n + row0;
+            // the mask tile reuses the obs tile: each wave finishes streaming its obs rows before it writes mask rows
+            stage_and_store<KIND>(lds, -1, o, mbits, obs_out ? obs_out + srow * D : nullptr, nullptr, n_valid_block,
+                                  tid - kPoEnvs);
+            stage_and_store<KIND>(lds, -1, o, mbits, nullptr, mask_out ? mask_out + srow * A : nullptr, n_valid_block,
+                                  tid - kPoEnvs);
         }
     }
 }
@@ -663,6 +873,7 @@ struct mse_env {
     bool noise_on;
     bool literal;                // evaluate every Generator.choice draw in literal fp64
     bool pipelined;              // mse_rollout uses the dynamics/observer kernel (k_rollout_po)
+    bool ring;                   // ... with RNG waves feeding an LDS ring (k_rollout_ring)
     uint64_t policy_t;
 };
 
@@ -816,6 +1027,21 @@ static int build_tables(const mse_config &c, Params &P, std::vector<uint32_t> &i
         for (int m = 0; m < 4; ++m) cst[CST_BASE_ACC0 + m] = c.baseline_accuracy[m];
         for (int k = 0; k < CST_COUNT; ++k) put_f64(cst[k]);
     }
+    P.off_jump = (int)image.size(); // even: only 8-byte items since off_cst
+    {
+        // LCG jump-ahead by 2^j steps: A = M^(2^j), G = 1 + M + ... + M^(2^j - 1)  (mod 2^128)
+        typedef unsigned __int128 u128;
+        u128 A = (((u128)0x2360ED051FC65DA4ull) << 64) | (u128)0x4385DF649FCCF645ull, G = 1;
+        for (int j = 0; j < kJumpBits; ++j) {
+            uint64_t w4[4] = {(uint64_t)A, (uint64_t)(A >> 64), (uint64_t)G, (uint64_t)(G >> 64)};
+            for (int q = 0; q < 4; ++q) {
+                image.push_back((uint32_t)w4[q]);
+                image.push_back((uint32_t)(w4[q] >> 32));
+            }
+            G = G * (A + 1); // G_{2n} = G_n (A_n + 1)
+            A = A * A;
+        }
+    }
     P.table_words = (int)image.size();
     if (P.table_words > 16384) {
         why = "container_capacity / bale_standard_size too large for the LDS-resident tables (64 KiB)";
@@ -859,6 +1085,21 @@ static void launch_rollout(mse_env *h, hipStream_t s, int k_steps, uint64_t poli
                            uint32_t flags, int32_t *actions, float *obs, float *rew, uint8_t *done, uint8_t *mask)
 {
     const bool lit = h->literal;
+    if (h->ring) {
+        const dim3 grid((unsigned)(h->P.n_pad / kPoEnvs));
+        const size_t table_bytes = (size_t)h->P.table_words * 4u;
+        const size_t lds_n = (size_t)RingLayout<KIND, true>::table_offset + table_bytes;
+        const size_t lds_p = (size_t)RingLayout<KIND, false>::table_offset + table_bytes;
+        if (h->noise_on)
+            hipLaunchKernelGGL((k_rollout_ring<KIND, true>), grid, dim3(kRingThreads), lds_n, s, h->P, h->planes,
+                               h->tables, k_steps, policy_seed, h->policy_t, sort_mode, flags, actions, obs, rew, done,
+                               mask);
+        else
+            hipLaunchKernelGGL((k_rollout_ring<KIND, false>), grid, dim3(kRingThreads), lds_p, s, h->P, h->planes,
+                               h->tables, k_steps, policy_seed, h->policy_t, sort_mode, flags, actions, obs, rew, done,
+                               mask);
+        return;
+    }
     if (h->pipelined) {
         const dim3 grid((unsigned)(h->P.n_pad / kPoEnvs));
         const size_t table_bytes = (size_t)h->P.table_words * 4u;
@@ -1012,7 +1253,39 @@ int mse_create_indexed(mse_env **out, const mse_config *cfg, int64_t n_envs, int
     h->literal = cfg->literal_choice != 0 || cfg->input_batch_size > 127;
     // rollout kernel: the pipelined one (dynamics + observer waves) pays off while a one-lane-per-env grid
     // leaves the SIMDs under two waves each; 0 = decide by size, 1 = always, 2 = never
-    h->pipelined = cfg->rollout_pipeline == 1 || (cfg->rollout_pipeline == 0 && n_envs <= 131072);
+    h->pipelined = cfg->rollout_pipeline == 1 || cfg->rollout_pipeline == 3 ||
+                   (cfg->rollout_pipeline == 0 && n_envs <= 131072);
+    {
+        // draws per step are bounded by the mis-sorted units of the two stations a mode leaves unboosted at the
+        // lowest accuracy the noise allows; the ring kernel needs that bound <= kRingMaxPerStep
+        // false_m = target - rint(target * acc) grows with target (<= the pattern's count) and falls with acc
+        // (>= clip(baseline [+ boost] - noise)); modes other than 0 / 1 (no boost) exist only for Env_2's
+        // externally supplied sorting decision
+        int worst = 0;
+        const int n_modes = cfg->env_kind == MSE_ENV_PRESS ? 3 : 2;
+        for (int k = 1; k <= 2; ++k) {
+            for (int mode = 0; mode < n_modes; ++mode) {
+                int sum = 0;
+                for (int m = 0; m < 4; ++m) {
+                    const bool boosted = mode == 0 ? (m == 0 || m == 2) : (mode == 1 ? (m == 1 || m == 3) : false);
+                    double acc = cfg->baseline_accuracy[m] + (boosted ? cfg->boost : 0.0) - cfg->noise;
+                    acc = acc < 0.0 ? 0.0 : (acc > 1.0 ? 1.0 : acc);
+                    const int cnt = (int)((P.pat_word[k] >> (8 * m)) & 0xFFu);
+                    sum += cnt - (int)std::nearbyint((double)cnt * acc);
+                }
+                worst = sum > worst ? sum : worst;
+            }
+        }
+        const bool fits = worst <= kRingMaxPerStep && !h->literal;
+        h->ring = h->pipelined && fits && cfg->rollout_pipeline != 1;
+        if (cfg->rollout_pipeline == 3 && !fits) {
+            (void)hipFree(h->planes);
+            (void)hipFree(h->err_count);
+            delete h;
+            return fail(MSE_ERR_UNSUPPORTED_CONFIG, "rollout_pipeline=3 (ring kernel) needs at most 31 draws per step "
+                                                    "and the integer draw path");
+        }
+    }
 
     size_t bytes = (size_t)PL_COUNT * (size_t)P.n_pad * sizeof(uint4);
     hipError_t e1 = hipMalloc(reinterpret_cast<void **>(&h->planes), bytes);

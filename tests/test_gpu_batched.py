@@ -171,23 +171,40 @@ def test_full_size_properties(kind, n):
 
 @pytest.mark.parametrize("kind", KINDS)
 @pytest.mark.parametrize("noise", [0.0, 0.05])
-def test_pipelined_rollout_equals_single_role_rollout(kind, noise):
-    """mse_rollout's two kernels (dynamics/observer pipeline vs one lane per env) give identical
-    buffers and identical final state; ragged N, several auto-resets, overflow checking on."""
+@pytest.mark.parametrize("pipeline", [1, 3])
+def test_pipelined_rollout_equals_single_role_rollout(kind, noise, pipeline):
+    """mse_rollout's kernels (1: dynamics/observer waves, 3: + RNG waves over an LDS ring, 2: one lane per env)
+    give identical buffers and identical final state (incl. the PCG64 stream position); ragged N, several
+    auto-resets, overflow checking on, single-step launches."""
     import torch
 
     n, K = 1000 + 37, 45
     kw = dict(base_seed=321, max_steps=20, noise_sorting=noise, balesize=200, auto_reset=True)
-    a = _mk(kind, n, rollout_pipeline=1, **kw)
+    a = _mk(kind, n, rollout_pipeline=pipeline, **kw)
     b = _mk(kind, n, rollout_pipeline=2, **kw)
     sm = (torch.arange(n, dtype=torch.int32, device="cuda") % 3 - 1) if kind == "press" else None  # -1 = rule
-    for chunk, ovf in ((K, False), (7, True), (1, False)):
+    for chunk, ovf in ((K, False), (7, True), (1, False), (16, False)):
         ra = a.rollout(chunk, policy_seed=11, sort_mode=sm, check_overflow=ovf)
         rb = b.rollout(chunk, policy_seed=11, sort_mode=sm, check_overflow=ovf)
         for key in ra:
             assert torch.equal(ra[key], rb[key]), (key, chunk)
-    for x, y in zip(a.get_state(), b.get_state()):
-        assert torch.equal(x, y)
+        for x, y in zip(a.get_state(), b.get_state()):
+            assert torch.equal(x, y), chunk
+
+
+def test_ring_kernel_refuses_configs_with_too_many_draws():
+    import marl_sortingenv_amd as M
+    from marl_sortingenv_amd._lib import MseError
+
+    cfg = M.SortingEnvConfig(baseline_accuracy=(0.3, 0.3, 0.3, 0.3), boost=0.2)  # ~50 mis-sorted units per step
+    with pytest.raises(MseError):
+        _mk("mono", 512, config=cfg, rollout_pipeline=3)
+    # automatic choice falls back to the dynamics/observer kernel and stays exact
+    a = _mk("mono", 512, config=cfg, base_seed=1, max_steps=30, noise_sorting=0.0)
+    b = _mk("mono", 512, config=cfg, base_seed=1, max_steps=30, noise_sorting=0.0, rollout_pipeline=2)
+    ra, rb = a.rollout(40, policy_seed=2), b.rollout(40, policy_seed=2)
+    for key in ra:
+        assert __import__("torch").equal(ra[key], rb[key]), key
 
 
 @pytest.mark.parametrize("kind", KINDS)

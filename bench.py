@@ -187,7 +187,7 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS, "traffic": measured_traffic(args, n, chunk),
-                "kernel": "k_rollout_po" if n <= 131072 else "k_rollout", "launch_ms": per_launch_ms,
+                "kernel": "k_rollout_ring" if n <= 131072 else "k_rollout", "launch_ms": per_launch_ms,
                 "algorithmic_bytes_per_env_step": bytes_per_step, "env_steps_per_launch": n * chunk,
             },
         }

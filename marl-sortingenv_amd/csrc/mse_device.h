@@ -577,17 +577,18 @@ struct RngLocal {
 };
 
 // Outputs produced ahead by an RNG wave into an LDS ring of the upper 32 bits (k_rollout_ring).
-// Output #p (p = 0, 1, ...) is the output of the state p+1 steps after `start`.  Layout: 16 chunks of
-// [256 lanes][4 words]; output #p of env slot el sits at ring[((p >> 2) & 15) * 1024 + el * 4 + (p & 3)].
+// Output #p (p = 0, 1, ...) is the output of the state p+1 steps after `start`.  Layout [64 outputs][256 env
+// slots]: output #p of env slot el sits at ring[(p & 63) * 256 + el] (a wave's lanes hit 64 different banks
+// whatever their positions).
 constexpr int kRingDepth = 64;        // outputs per env
 constexpr int kRingMaxPerStep = 31;   // the producer lags one barrier: two steps' draws must fit in the ring
 struct RngRing {
-    const uint32_t *lane_base; // ring + el * 4
+    const uint32_t *lane_base; // ring + el
     const uint64_t *jump_tab;
     Pcg start;                 // stream state when the launch began (never advanced)
     uint32_t pos;              // outputs consumed so far = index of the next one
     uint32_t nxt;              // prefetched output #pos
-    __device__ __forceinline__ uint32_t load(uint32_t p) const { return lane_base[((p >> 2) & 15u) * 1024u + (p & 3u)]; }
+    __device__ __forceinline__ uint32_t load(uint32_t p) const { return lane_base[(p & (uint32_t)(kRingDepth - 1)) * 256u]; }
     __device__ __forceinline__ void begin_step() { nxt = load(pos); }
     __device__ __forceinline__ uint32_t next_hi32()
     {

@@ -343,6 +343,7 @@ __global__ __launch_bounds__(kPoThreads) void k_rollout_po(Params P, uint4 *__re
 
     if (!observer) {
         // ------------------------------------------------------------------ dynamics waves
+        __builtin_amdgcn_s_setprio(3); // the critical path: win the issue arbitration over the observer wave
         const BaleRef bales{lbale + el, kPoEnvs};
         if (P.track_bales) {
 #pragma unroll
@@ -528,12 +529,15 @@ __global__ __launch_bounds__(kRingThreads) void k_rollout_ring(Params P, uint4 *
             g.i_lo = (uint64_t)b.x | ((uint64_t)b.y << 32);
             g.i_hi = (uint64_t)b.z | ((uint64_t)b.w << 32);
         }
-        uint32_t *base = lring + el * 4;
+        uint32_t *base = lring + el;
         uint32_t w = 0, target = live ? 32u : 0u; // enough for the first step (kRingMaxPerStep < 32)
         for (int s = -1; s < k_steps; ++s) {
+#ifdef MSE_ABL_RING_NOQ
+            w = target;
+#endif
             while (w < target) { // per-lane trip count: a lane tops its own ring up
                 pcg_advance(g);
-                base[((w >> 2) & 15u) * 1024u + (w & 3u)] = pcg_output_hi32(g);
+                base[(w & (uint32_t)(kRingDepth - 1)) * (uint32_t)kPoEnvs] = pcg_output_hi32(g);
                 w += 1u;
             }
             lds_barrier_all(); // s == -1: B_init (first outputs are in place); else B_s
@@ -542,6 +546,9 @@ __global__ __launch_bounds__(kRingThreads) void k_rollout_ring(Params P, uint4 *
         }
     } else if (role == 0) {
         // ------------------------------------------------------------------ dynamics waves
+        // the critical path of the pipeline: let their instructions win the SIMD's issue arbitration over the
+        // observer and RNG wave that share it
+        __builtin_amdgcn_s_setprio(3);
         const BaleRef bales{lbale + el, kPoEnvs};
         if (P.track_bales) {
 #pragma unroll
@@ -555,7 +562,7 @@ __global__ __launch_bounds__(kRingThreads) void k_rollout_ring(Params P, uint4 *
         }
         __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): no load is outstanding inside the step loop
         RngRing rng;
-        rng.lane_base = lring + el * 4;
+        rng.lane_base = lring + el;
         rng.jump_tab = tb.jump;
         rng.start = e.rng;
         rng.pos = 0;
@@ -638,6 +645,9 @@ __global__ __launch_bounds__(kRingThreads) void k_rollout_ring(Params P, uint4 *
             sn.lps = (int)((pk >> 22) & 1u);
             sn.done = (int)((pk >> 23) & 1u);
             sn.overflowed = (int)((pk >> 24) & 1u);
+#ifdef MSE_ABL_RING_NOO
+            if (sn.ce == 0x7fffffff)
+#endif
             if (live) { // the snapshot slots of padding lanes are never written
                 int k[4];
                 StepResult r = env_observe<KIND, NOISE>(sn, P, tb, k, o);
@@ -652,11 +662,16 @@ __global__ __launch_bounds__(kRingThreads) void k_rollout_ring(Params P, uint4 *
                 if (done_out != nullptr) done_out[(long long)s * P.n + i] = (uint8_t)r.done;
             }
             const long long srow = (long long)s * P.n + row0;
+#ifdef MSE_ABL_RING_NOO
+            if (sn.ce == 0x7fffffff)
+#endif
+            {
             // the mask tile reuses the obs tile: each wave finishes streaming its obs rows before it writes mask rows
             stage_and_store<KIND>(lds, -1, o, mbits, obs_out ? obs_out + srow * D : nullptr, nullptr, n_valid_block,
                                   tid - kPoEnvs);
             stage_and_store<KIND>(lds, -1, o, mbits, nullptr, mask_out ? mask_out + srow * A : nullptr, n_valid_block,
                                   tid - kPoEnvs);
+            }
         }
     }
 }

@@ -70,7 +70,9 @@ struct Params {
     float inv_balesize;           // 1.0f / bale_standard_size (quotient estimate, fixed up exactly)
     double max_state_reward;      // used every step: stays a kernel argument (SGPR pair)
     // stage vectors are one of three words: id 0 = empty (after reset), 1 / 2 = seasonal pattern
-    uint32_t pat_word[3];   // packed u8x4 counts A..D (load/store conversion only; the step reads the LDS copy)
+    uint32_t pat_word[3];   // packed u8x4 counts A..D (load/store conversion)
+    uint32_t pat_word1, pat_word2; // the same as two scalars: a per-lane choice between them is two v_cndmask on
+                                   // SGPRs (indexing the array per lane would be a global load)
     int thr_sev, thr_mild;  // levels above these have fill_ratio > 0.95 / > 0.90 (literal fp64 scan on the host)
     int sev_negative, mild_negative; // overflow_penalty_severe / _mild < 0 (then that bracket returns early)
     int k_thr[4];           // hundredths of python round(quality_threshold, 2): purity of an empty container
@@ -1039,7 +1041,8 @@ __device__ __forceinline__ void env_dynamics(Env &e, RNG &rng, const Params &P, 
     // input_action_rules draws rng_input.integers(60,81) and discards it (env_super.py:911-922, :433);
     // that stream is never observed, so it is not carried.
     update_environment(e);
-    const uint32_t sorting_word = tb.pat[e.st_sort * kPatStride]; // issued first, needed at the first station
+    const uint32_t pw1 = P.pat_word1, pw2 = P.pat_word2;
+    const uint32_t sorting_word = e.st_sort == 1 ? pw1 : (e.st_sort == 2 ? pw2 : 0u); // current_material_sorting
 
     int sort_mode, press_action = 0;
     bool run_press_rules = true;

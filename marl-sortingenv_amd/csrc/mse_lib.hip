@@ -955,6 +955,8 @@ static int build_tables(const mse_config &c, Params &P, std::vector<uint32_t> &i
         }
         pat_rec[k][2] = (pr[0] + pr[2] > pr[1] + pr[3]) ? 0u : 1u;                               // env_super.py:479-482
     }
+    P.pat_word1 = P.pat_word[1];
+    P.pat_word2 = P.pat_word[2];
     if (P.pat_word[1] == P.pat_word[2] || P.pat_word[1] == 0 || P.pat_word[2] == 0) {
         why = "the two seasonal patterns must give distinct, non-empty material counts";
         return MSE_ERR_UNSUPPORTED_CONFIG;

@@ -14,8 +14,10 @@ EXPORTS = [
     "mse_version", "mse_last_error", "mse_status_string", "mse_config_default", "mse_create",
     "mse_create_indexed", "mse_destroy", "mse_num_envs", "mse_obs_dim", "mse_num_actions", "mse_reset",
     "mse_step", "mse_action_masks", "mse_rollout", "mse_sample_actions", "mse_rule_actions", "mse_get_state", "mse_set_state",
-    "mse_error_count", "mse_algorithmic_bytes_per_step",
+    "mse_error_count", "mse_algorithmic_bytes_per_step", "mse_tie_window",
 ]
+
+_other_libs: dict = {}
 
 
 class MseError(RuntimeError):
@@ -51,20 +53,24 @@ def library_path() -> str:
     return LIB_PATH
 
 
-def load_library() -> C.CDLL:
-    """Loads the in-tree libmse_hip.so; raises if it has not been built (python -m ... build)."""
+def load_library(path: str | None = None) -> C.CDLL:
+    """Loads the in-tree libmse_hip.so; raises if it has not been built (python -m ... build).
+    `path` names another build of the same source (tests load libmse_hip_widetie.so beside the product)."""
     global _lib
-    if _lib is not None:
+    if path is None and _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    if path is not None and path in _other_libs:
+        return _other_libs[path]
+    lib_path = LIB_PATH if path is None else path
+    if not os.path.exists(lib_path):
         raise ImportError(
-            f"{LIB_PATH} is missing: build it with `python __graft_entry__.py` or "
+            f"{lib_path} is missing: build it with `python __graft_entry__.py` or "
             "`python marl-sortingenv_amd/build.py`. There is no CPU fallback for the step path.")
     # PyTorch-ROCm bundles its own HIP runtime (same SONAME as ROCm's). Import it first so that
     # libmse_hip.so binds to the runtime torch uses: streams and device pointers are shared objects.
     import torch  # noqa: F401
 
-    L = C.CDLL(LIB_PATH)
+    L = C.CDLL(lib_path)
     vp, i32, i64, u32, u64 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32, C.c_uint64
     L.mse_version.restype = C.c_int
     L.mse_last_error.restype = C.c_char_p
@@ -90,7 +96,11 @@ def load_library() -> C.CDLL:
     L.mse_algorithmic_bytes_per_step.argtypes = [vp]
     for name in EXPORTS:
         getattr(L, name)  # AttributeError if the library does not export what include/mse.h declares
-    _lib = L
+    L.mse_tie_window.restype = u32
+    if path is None:
+        _lib = L
+    else:
+        _other_libs[path] = L
     return L
 
 

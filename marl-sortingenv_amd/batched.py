@@ -35,12 +35,12 @@ class BatchedSortingEnv:
                  noise_sorting: Optional[float] = 0.05, balesize: Optional[int] = 200,
                  config: Optional[SortingEnvConfig] = None, auto_reset: bool = True,
                  track_bales: bool = True, literal_choice: bool = False, index_offset: int = 0,
-                 reset_now: bool = True, rollout_pipeline: int = 0):
+                 reset_now: bool = True, rollout_pipeline: int = 0, library: Optional[str] = None):
         if kind not in OBS_DIM:
             raise ValueError(f"kind must be one of {sorted(OBS_DIM)}")
         if not torch.cuda.is_available():
             raise RuntimeError("BatchedSortingEnv needs a HIP device: the step path has no CPU fallback")
-        self.L = load_library()
+        self.L = load_library(library)  # `library`: another build of the same source (tests)
         self.kind = self.name = kind
         self.num_envs = int(num_envs)
         self.device = torch.device("cuda", device) if isinstance(device, int) else torch.device(device)

@@ -42,5 +42,21 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     return LIB_PATH
 
 
+# Test-only variant: the near-tie window of the integer `choice` decision widened from 2^-23 to 2^-5 of the
+# draws, so the literal-cdf branches (and the ring kernel's redo of a whole step) run all the time.
+WIDETIE_LIB_PATH = os.path.join(PKG_DIR, "libmse_hip_widetie.so")
+
+
+def build_widetie_library(force: bool = False) -> str:
+    if not force and os.path.exists(WIDETIE_LIB_PATH) and \
+            all(os.path.getmtime(p) <= os.path.getmtime(WIDETIE_LIB_PATH) for p in SOURCES + HEADERS):
+        return WIDETIE_LIB_PATH
+    cmd = [hipcc_path(), *HIPCC_FLAGS, "-DMSE_TIE_WINDOW=0x08000000u", "-I", os.path.join(REPO_ROOT, "include"),
+           *SOURCES, "-o", WIDETIE_LIB_PATH]
+    subprocess.run(cmd, check=True)
+    return WIDETIE_LIB_PATH
+
+
 if __name__ == "__main__":
+    print(build_widetie_library(force=True))
     print(build_library(force=True, verbose=True))

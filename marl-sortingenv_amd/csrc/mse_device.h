@@ -78,6 +78,7 @@ struct Params {
     int k_thr[4];           // hundredths of python round(quality_threshold, 2): purity of an empty container
     // offsets (in 4-byte words) into the table image; see build_tables
     int off_lvl, off_pdiff, off_timer0, off_timer1, off_tanh, off_eff, off_pat, off_acc, off_bonus, off_ptime, off_cst, off_jump, table_words;
+    int ring_worst; // most sort_material draws one step can make with this config (k_rollout_ring flow control)
 };
 
 // ------------------------------------------------------------------------------------------
@@ -276,7 +277,48 @@ __device__ __forceinline__ int select_kth_bit(uint32_t bits, int k)
 // ------------------------------------------------------------------------------------------
 // per-env register image
 // ------------------------------------------------------------------------------------------
+// Diagnostic build only (-DMSE_TIMELINE, tools/timeline.py): s_memtime deltas per section and role, summed
+// into a device symbol by lane 0 of every wave.  The shipped library compiles none of this.
+#ifdef MSE_TIMELINE
+__device__ unsigned long long g_timeline[3 * 8];
+struct Timeline {
+    unsigned long long last;
+    unsigned long long acc[8];
+    __device__ __forceinline__ void start()
+    {
+        for (int k = 0; k < 8; ++k) acc[k] = 0;
+        last = __builtin_readcyclecounter();
+    }
+    __device__ __forceinline__ void mark(int k)
+    {
+        if (blockIdx.x != 0) return; // s_memtime from every wave of the chip serialises: sample one workgroup
+        const unsigned long long now = __builtin_readcyclecounter();
+        acc[k] += now - last;
+        last = now;
+    }
+    __device__ __forceinline__ void flush(int role) const
+    {
+        if ((threadIdx.x & 63) == 0 && blockIdx.x == 0)
+            for (int k = 0; k < 8; ++k) atomicAdd(&g_timeline[role * 8 + k], acc[k]);
+    }
+};
+// MSE_TIMELINE = 1: every section; 2: only the barrier waits (two reads per step, little disturbance)
+#if MSE_TIMELINE == 2
+#define MSE_TL(tl, k) ((void)0)
+#define MSE_TLB(tl, k) (tl).mark(k)
+#else
+#define MSE_TL(tl, k) (tl).mark(k)
+#define MSE_TLB(tl, k) (tl).mark(k)
+#endif
+#else
+#define MSE_TLB(tl, k) ((void)0)
+#define MSE_TL(tl, k) ((void)0)
+#endif
+
 struct Env {
+#ifdef MSE_TIMELINE
+    Timeline tl;
+#endif
     Pcg rng;            // seed+99: sort_material
     Pcg noise;          // seed+4 : update_accuracy (noise > 0)
     Pcg press;          // seed+3 : Env_1's internal press sampling
@@ -580,31 +622,48 @@ struct RngLocal {
 
 // Outputs produced ahead by an RNG wave into an LDS ring of the upper 32 bits (k_rollout_ring).
 // Output #p (p = 0, 1, ...) is the output of the state p+1 steps after `start`.  Layout [64 outputs][256 env
-// slots]: output #p of env slot el sits at ring[(p & 63) * 256 + el] (a wave's lanes hit 64 different banks
+// slots]: output #p of env slot el sits at row p & 63, column el (a wave's lanes hit 64 different banks
 // whatever their positions).
 constexpr int kRingDepth = 64;        // outputs per env
 constexpr int kRingMaxPerStep = 31;   // the producer lags one barrier: two steps' draws must fit in the ring
+typedef __attribute__((address_space(3))) const uint32_t *lds_u32_ptr;
 struct RngRing {
-    const uint32_t *lane_base; // ring + el
+    uint32_t lane_addr;        // LDS byte address of the env slot's column; the ring itself is 64 KiB aligned
     const uint64_t *jump_tab;
     Pcg start;                 // stream state when the launch began (never advanced)
-    uint32_t pos;              // outputs consumed so far = index of the next one
-    uint32_t nxt;              // prefetched output #pos
-    __device__ __forceinline__ uint32_t load(uint32_t p) const { return lane_base[(p & (uint32_t)(kRingDepth - 1)) * 256u]; }
-    __device__ __forceinline__ void begin_step() { nxt = load(pos); }
+    uint32_t p10;              // outputs consumed so far (= index of the next one), times 1024
+    uint32_t nxt, nxt2;        // prefetched outputs #pos and #pos+1
+    uint32_t f_min, f_max;     // extremes of the step's fraction views f (near-tie monitor, see draw_units_ring)
+#ifdef MSE_TIMELINE
+    Timeline *tl;
+#endif
+    __device__ __forceinline__ uint32_t pos() const { return p10 >> 10; }
+    // row (pos & 63) of the column: one v_and_or_b32
+    __device__ __forceinline__ uint32_t load(uint32_t q10) const
+    {
+        return *(lds_u32_ptr)(uintptr_t)((q10 & 0xFC00u) | lane_addr);
+    }
+    __device__ __forceinline__ void begin_step()
+    {
+        nxt = load(p10); // after the step's barrier: everything this step can consume is in the ring
+        nxt2 = load(p10 + 1024u);
+        f_min = 0xFFFFFFFFu;
+        f_max = 0u;
+    }
+};
+
+// a generator positioned by jump-ahead that counts what it hands out (literal redo of a ring step)
+struct RngCounted {
+    Pcg g;
+    uint32_t count;
+    __device__ __forceinline__ void begin_step() {}
     __device__ __forceinline__ uint32_t next_hi32()
     {
-        const uint32_t v = nxt;
-        pos += 1u;
-        nxt = load(pos); // issued a whole decision ahead of its use
-        return v;
+        pcg_advance(g);
+        ++count;
+        return pcg_output_hi32(g);
     }
-    __device__ __forceinline__ uint64_t last_full() const
-    {
-        Pcg g = start;
-        pcg_jump(g, pos, jump_tab); // the state whose output was just consumed
-        return pcg_output(g);
-    }
+    __device__ __forceinline__ uint64_t last_full() const { return pcg_output(g); }
 };
 
 // env_super.py:511-609 sort_material.
@@ -618,6 +677,13 @@ struct RngRing {
 // Byte k of D = (0x80 + v) - c_k keeps bit 7 iff c_k <= v; the chosen bin is the first k with c_k > v and
 // removing one unit there lowers every prefix sum from k on by one: C += (flags >> 7) - 0x01010101.
 // If f is within a wide margin of 0 or 2^32 the literal fp64 path decides instead (DESIGN.md "choice").
+// A draw is "near a tie" when f + 0x200 < MSE_TIE_WINDOW, i.e. f < 16 or f >= 2^32 - 512 with the shipped
+// window.  libmse_hip_widetie.so (tests only) is the same source with a window ~10^5 times wider, so that the
+// literal branches run on a few percent of the draws and are held to the same golden vectors.
+#ifndef MSE_TIE_WINDOW
+#define MSE_TIE_WINDOW 0x210u
+#endif
+
 template <bool LITERAL, class RNG>
 __device__ __forceinline__ void draw_units(RNG &rng, uint32_t &C, int &rem)
 {
@@ -636,7 +702,7 @@ __device__ __forceinline__ void draw_units(RNG &rng, uint32_t &C, int &rem)
             const uint32_t f = (uint32_t)prod;
             const uint32_t v = (uint32_t)(prod >> 32);
             flags = ((__umul24(v, 0x010101u) | 0x00808080u) - C) & 0x00808080u; // bytes 0..2 only; v < 128
-            literal = (f + 0x200u) < 0x210u; // f < 16 or f >= 2^32 - 512
+            literal = (f + 0x200u) < MSE_TIE_WINDOW;
         }
         if (__builtin_expect(literal, 0)) { // ~1e-7 per draw: keep it out of the loop's straight line
             const int sel = choice4_literal(C, rng.last_full());
@@ -648,6 +714,94 @@ __device__ __forceinline__ void draw_units(RNG &rng, uint32_t &C, int &rem)
 }
 
 // station I: true = rint(target * acc), false = target - true, leftover[I] = false (env_super.py:535-546)
+// The draw loop when the outputs come from the LDS ring.
+//
+// The dynamics wave is one wave on its SIMD that matters (the observer and RNG waves have slack), and a single
+// wave issues one instruction per ~5 cycles at best, ~9 if it depends on the previous one: what counts is the
+// number of instructions per draw and that no two neighbours depend on each other.  The structured loop the
+// compiler builds from C++ (two exits, phi copies, exec bookkeeping) costs ~27 instructions per draw; this
+// hand-placed one 14 (tools/ubench/ubench_draw.hip: 179 -> 101 cycles per draw).  Per draw:
+//   * T is tracked beside C (each draw lowers both by one); the product r * T of the NEXT draw is formed one
+//     draw ahead (its T is known), so the loop-carried chain is only  Cb -> sub -> shift -> and -> add3;
+//   * D = (V | 0x808080) - C is carried with the bias folded in (Cb = C - 0x808080); the broadcast of v is a
+//     byte permute;
+//   * two ring outputs are in flight in two fixed registers (the body is unrolled twice; lanes that make an
+//     odd number of draws swap the pair on the way out), prefetched with a two-instruction address;
+//   * the near-tie test is only *recorded* (min and max of the fraction view f, folded in once per two draws):
+//     sort_material looks at them once per step and, about once in 10^6 steps, redoes the step literally.
+// On entry and exit rng.nxt / rng.nxt2 hold outputs #pos and #pos+1 (read after the step's barrier).
+// The two products live in v[124:127]: inline asm cannot name the halves of a 64-bit operand.
+#define MSE_RING_DRAW(PIN_HI, POUT, OUSE, OLOAD, EXTRA)        \
+    "v_perm_b32 %[x], 0, " PIN_HI ", %[sel]\n\t"              \
+    "v_add_u32 %[p10], 0x400, %[p10]\n\t"                     \
+    "v_add_u32 %[t], -1, %[t]\n\t"                            \
+    "v_sub_u32 %[x], %[x], %[cb]\n\t"                         \
+    "v_and_or_b32 %[a], %[p10], %[mask], %[lane]\n\t"         \
+    "v_cmp_ne_u32_e64 %[cm], %[t], %[tend]\n\t"               \
+    "v_lshrrev_b32 %[x], 7, %[x]\n\t"                         \
+    "ds_read_b32 %[" OLOAD "], %[a]\n\t"                      \
+    EXTRA                                                      \
+    "s_waitcnt lgkmcnt(1)\n\t"                                \
+    "v_and_b32 %[x], 0x10101, %[x]\n\t"                       \
+    "v_mad_u64_u32 " POUT ", %[dm], %[" OUSE "], %[t], 0\n\t" \
+    "v_add3_u32 %[cb], %[cb], %[x], %[k]\n\t"                 \
+    "s_and_b64 exec, exec, %[cm]\n\t"
+
+__device__ __forceinline__ void draw_units_ring(RngRing &rng, uint32_t &C, int &rem)
+{
+#ifdef MSE_ABL_NODRAW
+    rem = 0;
+#endif
+#ifdef MSE_TIMELINE
+    rng.tl->mark(2); // everything of sort_material outside the draw loops
+#endif
+    uint32_t T = C >> 24;
+    const uint32_t n_draws = (uint32_t)rem;  // rem <= T: a station's own false units are in the pool
+    const uint32_t T_end = T - n_draws;
+    uint32_t Cb = C - 0x00808080u;
+    uint32_t x, a;
+    uint64_t sv, cm, dm;
+    const uint32_t kMask = 0xFC00u, kSel = 0x0C000000u, kK = 0xFEFEFEFFu;
+    asm volatile(
+        "s_mov_b64 %[sv], exec\n\t"
+        "v_cmp_ne_u32 vcc, 0, %[n]\n\t"
+        "s_and_b64 exec, exec, vcc\n\t"
+        "s_cbranch_execz 3f\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"                         /* nothing but this loop's reads is counted below */
+        "v_mad_u64_u32 v[124:125], %[dm], %[o0], %[t], 0\n\t"
+        "v_add_u32 %[p10], 0x400, %[p10]\n"                /* the next read is output #pos+2 */
+        "1:\n\t"
+        MSE_RING_DRAW("v125", "v[126:127]", "o1", "o0", "")
+        "s_cbranch_execz 2f\n\t"
+        MSE_RING_DRAW("v127", "v[124:125]", "o0", "o1",
+                      "v_min3_u32 %[mn], %[mn], v124, v126\n\tv_max3_u32 %[mx], %[mx], v124, v126\n\t")
+        "s_cbranch_execnz 1b\n"
+        "2:\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "s_mov_b64 exec, %[sv]\n\t"
+        "v_and_b32 %[x], 1, %[n]\n\t"
+        "v_cmp_ne_u32 vcc, 0, %[x]\n\t"                    /* an odd number of draws: the pair is swapped and   */
+        "s_and_b64 exec, exec, vcc\n\t"                     /* the last f is not in the monitor yet             */
+        "v_swap_b32 %[o0], %[o1]\n\t"
+        "v_min_u32 %[mn], %[mn], v124\n\t"
+        "v_max_u32 %[mx], %[mx], v124\n\t"
+        "s_mov_b64 exec, %[sv]\n\t"
+        "v_cmp_ne_u32 vcc, 0, %[n]\n\t"                     /* lanes that drew at all ran p10 one ahead */
+        "s_and_b64 exec, exec, vcc\n\t"
+        "v_add_u32 %[p10], 0xfffffc00, %[p10]\n"
+        "3:\n\t"
+        "s_mov_b64 exec, %[sv]"
+        : [p10] "+v"(rng.p10), [x] "=&v"(x), [a] "=&v"(a), [o0] "+v"(rng.nxt), [o1] "+v"(rng.nxt2), [cb] "+v"(Cb),
+          [t] "+v"(T), [mn] "+v"(rng.f_min), [mx] "+v"(rng.f_max), [sv] "=&s"(sv), [cm] "=&s"(cm), [dm] "=&s"(dm)
+        : [sel] "s"(kSel), [mask] "s"(kMask), [lane] "v"(rng.lane_addr), [k] "s"(kK), [tend] "v"(T_end), [n] "v"(n_draws)
+        : "vcc", "memory", "v124", "v125", "v126", "v127");
+    C = Cb + 0x00808080u;
+    rem = 0;
+#ifdef MSE_TIMELINE
+    rng.tl->mark(7); // the draw loops
+#endif
+}
+
 template <int I>
 __device__ __forceinline__ void station_split(Env &e, uint32_t &C, const double acc_sorter[4], int &rem)
 {
@@ -687,6 +841,50 @@ __device__ __forceinline__ void sort_material(Env &e, RNG &rng, uint32_t sorting
     station_pair<LITERAL, 0>(e, rng, C, acc_sorter);
     station_pair<LITERAL, 2>(e, rng, C, acc_sorter);
     e.ce += (int)(C >> 24); // env_super.py:579,597
+}
+
+template <int I>
+__device__ __forceinline__ void station_pair_ring(Env &e, RngRing &rng, uint32_t &C, const double acc_sorter[4])
+{
+    int rem;
+    station_split<I>(e, C, acc_sorter, rem);
+    const bool early = rem == 0;
+    if (early) station_split<I + 1>(e, C, acc_sorter, rem);
+    draw_units_ring(rng, C, rem);
+    if (!early) {
+        station_split<I + 1>(e, C, acc_sorter, rem);
+        draw_units_ring(rng, C, rem);
+    }
+}
+
+// sort_material on the ring source (overload chosen for RngRing).
+template <bool LITERAL>
+__device__ __forceinline__ void sort_material(Env &e, RngRing &rng, uint32_t sorting_word, const double acc_sorter[4])
+{
+    static_assert(!LITERAL, "the ring carries only the upper 32 output bits");
+    const uint32_t p10_0 = rng.p10;
+    const int ct0 = e.ct[0], ct1 = e.ct[1], ct2 = e.ct[2], ct3 = e.ct[3];
+    const int cf0 = e.cf[0], cf1 = e.cf[1], cf2 = e.cf[2], cf3 = e.cf[3];
+    const int ce0 = e.ce;
+    rng.begin_step();
+    uint32_t C = sorting_word * 0x01010101u;
+    station_pair_ring<0>(e, rng, C, acc_sorter);
+    station_pair_ring<2>(e, rng, C, acc_sorter);
+    e.ce += (int)(C >> 24);
+    // near a tie: f < window - 0x200 or f >= 2^32 - 0x200  (f + 0x200 < window, as in draw_units)
+    if (__builtin_expect(rng.f_min < MSE_TIE_WINDOW - 0x200u || rng.f_max >= 0xFFFFFE00u, 0)) {
+        // some draw of this step sat within the margin of a cdf boundary: take the step again from the
+        // saved counters with every decision made by the literal fp64 cdf on the full 64-bit outputs
+        e.ct[0] = ct0; e.ct[1] = ct1; e.ct[2] = ct2; e.ct[3] = ct3;
+        e.cf[0] = cf0; e.cf[1] = cf1; e.cf[2] = cf2; e.cf[3] = cf3;
+        e.ce = ce0;
+        RngCounted exact;
+        exact.g = rng.start;
+        exact.count = 0;
+        pcg_jump(exact.g, p10_0 >> 10, rng.jump_tab);
+        sort_material<true>(e, exact, sorting_word, acc_sorter);
+        rng.p10 = p10_0 + (exact.count << 10);
+    }
 }
 
 // buffered uint32 of PCG64 (pcg64.h pcg64_next32)
@@ -1062,9 +1260,11 @@ __device__ __forceinline__ void env_dynamics(Env &e, RNG &rng, const Params &P, 
 
     double acc_sorter[4];
     update_accuracy<NOISE>(e, tb.cst, tb.acc, sort_mode, acc_sorter);
+    MSE_TL(e.tl, 1);
 #ifndef MSE_ABL_NOSORT
     sort_material<LITERAL>(e, rng, sorting_word, acc_sorter);
 #endif
+    MSE_TL(e.tl, 2);
 
     if (KIND == 1) {
         press_action = sample_masked_press_action(e, P); // env_1_sort.py:125-126 (mask before the tick)
@@ -1075,6 +1275,7 @@ __device__ __forceinline__ void env_dynamics(Env &e, RNG &rng, const Params &P, 
 #ifndef MSE_ABL_NOPRESS
     if (run_press_rules) press_action_rules(e, P, tb.cst, press_action, bales);
 #endif
+    MSE_TL(e.tl, 3);
 
     // snapshot for the observer
 #pragma unroll
@@ -1109,6 +1310,7 @@ __device__ __forceinline__ void env_dynamics(Env &e, RNG &rng, const Params &P, 
     e.step += 1;
     sn.overflowed = overflowed ? 1 : 0;
     sn.done = (overflowed || e.step >= P.max_steps) ? 1 : 0;
+    MSE_TL(e.tl, 4);
 }
 
 struct StepResult {

@@ -477,14 +477,16 @@ template <int KIND, bool NOISE>
 struct RingLayout {
     static constexpr int D = Dims<KIND>::D, A = Dims<KIND>::A;
     static constexpr int snap_words = kSnapWordsBase + (NOISE ? 4 : 0); // accuracy_belt travels as 4 x f32
+    static constexpr int ring_offset = 0;                               // 64 KiB aligned: RngRing::load masks the row in
+    static constexpr int ring_bytes = kRingDepth * kPoEnvs * 4;
+    static_assert(ring_bytes == 65536, "RngRing::load assumes 64 rows of 1 KiB");
+    static constexpr int stage_offset = ring_bytes;
     static constexpr int stage_bytes = kPoEnvs * D * 4;                 // obs tile; the mask tile reuses it
-    static constexpr int snap_offset = stage_bytes;
+    static constexpr int snap_offset = stage_offset + stage_bytes;
     static constexpr int snap_bytes = 2 * snap_words * kPoEnvs * 4;
     static constexpr int bale_offset = snap_offset + snap_bytes;
     static constexpr int bale_bytes = 5 * kPoEnvs * 16;
-    static constexpr int ring_offset = bale_offset + bale_bytes;
-    static constexpr int ring_bytes = kRingDepth * kPoEnvs * 4;
-    static constexpr int pos_offset = ring_offset + ring_bytes;
+    static constexpr int pos_offset = bale_offset + bale_bytes;
     static constexpr int pos_bytes = kPoEnvs * 4;
     static constexpr int table_offset = pos_offset + pos_bytes; // multiple of 16
 };
@@ -530,20 +532,51 @@ __global__ __launch_bounds__(kRingThreads) void k_rollout_ring(Params P, uint4 *
             g.i_hi = (uint64_t)b.z | ((uint64_t)b.w << 32);
         }
         uint32_t *base = lring + el;
-        uint32_t w = 0, target = live ? 32u : 0u; // enough for the first step (kRingMaxPerStep < 32)
+        // Production is demand-driven.  After B_s the lane knows r_s (outputs consumed through step s); the
+        // outputs of step s+1 (< r_s + worst) are in place already, those of step s+2 (< r_s + 2 worst) must be
+        // before B_{s+1}: that is `need`.  `cap` is how far a lane may run ahead: the ring's 64 slots, but
+        // never past what the remaining steps of this launch can consume.  The wave keeps going while ANY lane
+        // is below its need and every lane below its cap produces along, so a lane that drew a lot last step
+        // does not cost the wave max(draws) iterations every step: the run-ahead slack (64 - 2 worst) smooths
+        // the per-step spread (6 or 19 draws with the default config) towards the long-run mean.
+        const uint32_t worst = (uint32_t)P.ring_worst;
+        uint32_t w = 0, need = live ? worst : 0u, cap = need; // step 0's outputs, in place before B_init
+#ifdef MSE_TIMELINE
+        Timeline tl;
+        tl.start();
+#endif
         for (int s = -1; s < k_steps; ++s) {
 #ifdef MSE_ABL_RING_NOQ
-            w = target;
+            w = cap > w ? cap : w;
 #endif
-            while (w < target) { // per-lane trip count: a lane tops its own ring up
+            // M = the largest shortfall in the wave (a 6-bit maximum found bit by bit with ballots, in SGPRs);
+            // every lane then produces min(M, its room): a plain per-lane trip count for the loop below
+            const uint32_t deficit = need > w ? need - w : 0u; // <= 2 worst <= 62
+            uint32_t M = 0;
+#pragma unroll
+            for (int bit = 5; bit >= 0; --bit) {
+                const uint32_t cand = M | (1u << bit);
+                if (__builtin_amdgcn_ballot_w64(deficit >= cand) != 0ull) M = cand;
+            }
+            const uint32_t room = cap > w ? cap - w : 0u;
+            const uint32_t target = w + (M < room ? M : room);
+            while (w < target) {
                 pcg_advance(g);
                 base[(w & (uint32_t)(kRingDepth - 1)) * (uint32_t)kPoEnvs] = pcg_output_hi32(g);
                 w += 1u;
             }
+            MSE_TLB(tl, 0);
             lds_barrier_all(); // s == -1: B_init (first outputs are in place); else B_s
-            if (s + 1 < k_steps || s == -1) target = live ? lpos[el] + (uint32_t)kRingDepth : 0u;
-            if (s == -1) target = live ? (uint32_t)kRingDepth : 0u; // nothing consumed yet
+            MSE_TLB(tl, 1);
+            const uint32_t steps_left = (uint32_t)(k_steps - 1 - s); // steps s+1 .. K-1
+            const uint32_t r = lpos[el];                             // 0 at B_init
+            const uint32_t ahead = worst * steps_left;
+            need = live ? r + worst * (steps_left < 2u ? steps_left : 2u) : 0u;
+            cap = live ? r + (ahead < (uint32_t)kRingDepth ? ahead : (uint32_t)kRingDepth) : 0u;
         }
+#ifdef MSE_TIMELINE
+        tl.flush(2);
+#endif
     } else if (role == 0) {
         // ------------------------------------------------------------------ dynamics waves
         // the critical path of the pipeline: let their instructions win the SIMD's issue arbitration over the
@@ -562,18 +595,28 @@ __global__ __launch_bounds__(kRingThreads) void k_rollout_ring(Params P, uint4 *
         }
         __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): no load is outstanding inside the step loop
         RngRing rng;
-        rng.lane_base = lring + el;
+        rng.lane_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)(lring + el);
+        if ((rng.lane_addr & 0xFC00u) != 0u) __builtin_trap(); // the ring must start on a 64 KiB LDS boundary
         rng.jump_tab = tb.jump;
         rng.start = e.rng;
-        rng.pos = 0;
-        rng.nxt = 0;
+        rng.p10 = 0;
+        rng.nxt = rng.nxt2 = 0;
+#ifdef MSE_TIMELINE
+        rng.tl = &e.tl;
+#endif
+        rng.f_min = 0xFFFFFFFFu;
+        rng.f_max = 0u;
         uint32_t cur_mask = live ? action_mask_bits<KIND>(e, P) : 1u;
         lpos[el] = 0;
         lds_barrier_all(); // B_init
+#ifdef MSE_TIMELINE
+        e.tl.start();
+#endif
         for (int s = 0; s < k_steps; ++s) {
             if (live) { // padding lanes only keep the barrier count
                 const int a = policy_action<KIND>(e, cur_mask, tb, flags, policy_seed, (uint64_t)(P.index_offset + i),
                                                   policy_t0 + (uint64_t)s);
+                MSE_TL(e.tl, 0);
                 Snap sn;
                 env_dynamics<KIND, NOISE, false>(e, rng, P, tb, a, sm, flags, bales, sn);
                 if (__builtin_expect(sn.done != 0, 0)) { // all envs of a batch finish together: rare, wave-uniform
@@ -599,12 +642,17 @@ __global__ __launch_bounds__(kRingThreads) void k_rollout_ring(Params P, uint4 *
 #pragma unroll
                     for (int m = 0; m < 4; ++m) w[(13 + m) * kPoEnvs] = __float_as_uint((float)sn.acc[m]);
                 }
-                lpos[el] = rng.pos; // r_s for the RNG lane of this env
+                lpos[el] = rng.pos(); // r_s for the RNG lane of this env
             }
+            MSE_TLB(e.tl, 5);
             lds_barrier_all(); // B_s
+            MSE_TLB(e.tl, 6);
         }
+#ifdef MSE_TIMELINE
+        e.tl.flush(0);
+#endif
         if (live) {
-            pcg_jump(e.rng, rng.pos, tb.jump); // the stream position after everything this launch consumed
+            pcg_jump(e.rng, rng.pos(), tb.jump); // the stream position after everything this launch consumed
             store_env<KIND, NOISE>(e, planes, P, i, false);
         }
         if (P.track_bales) {
@@ -619,8 +667,13 @@ __global__ __launch_bounds__(kRingThreads) void k_rollout_ring(Params P, uint4 *
 #pragma unroll
         for (int j = 0; j < D; ++j) o[j] = 0.0f;
         lds_barrier_all(); // B_init
+#ifdef MSE_TIMELINE
+        Timeline tl;
+        tl.start();
+#endif
         for (int s = 0; s < k_steps; ++s) {
             lds_barrier_all(); // B_s: the snapshot of step s is complete
+            MSE_TLB(tl, 0);
             const uint32_t *w = lsnap + (s & 1) * SW * kPoEnvs + el;
             Snap sn;
 #pragma unroll
@@ -661,18 +714,23 @@ __global__ __launch_bounds__(kRingThreads) void k_rollout_ring(Params P, uint4 *
                 if (reward_out != nullptr) reward_out[(long long)s * P.n + i] = (float)r.reward;
                 if (done_out != nullptr) done_out[(long long)s * P.n + i] = (uint8_t)r.done;
             }
+            MSE_TL(tl, 1);
             const long long srow = (long long)s * P.n + row0;
 #ifdef MSE_ABL_RING_NOO
             if (sn.ce == 0x7fffffff)
 #endif
             {
             // the mask tile reuses the obs tile: each wave finishes streaming its obs rows before it writes mask rows
-            stage_and_store<KIND>(lds, -1, o, mbits, obs_out ? obs_out + srow * D : nullptr, nullptr, n_valid_block,
+            stage_and_store<KIND>(lds + L::stage_offset, -1, o, mbits, obs_out ? obs_out + srow * D : nullptr, nullptr, n_valid_block,
                                   tid - kPoEnvs);
-            stage_and_store<KIND>(lds, -1, o, mbits, nullptr, mask_out ? mask_out + srow * A : nullptr, n_valid_block,
+            stage_and_store<KIND>(lds + L::stage_offset, -1, o, mbits, nullptr, mask_out ? mask_out + srow * A : nullptr, n_valid_block,
                                   tid - kPoEnvs);
             }
+            MSE_TLB(tl, 2);
         }
+#ifdef MSE_TIMELINE
+        tl.flush(1);
+#endif
     }
 }
 
@@ -1149,6 +1207,18 @@ static void launch_rollout(mse_env *h, hipStream_t s, int k_steps, uint64_t poli
 extern "C" {
 
 int mse_version(void) { return MSE_VERSION; }
+uint32_t mse_tie_window(void) { return MSE_TIE_WINDOW; }
+#ifdef MSE_TIMELINE
+// diagnostic build: read and clear the per-role section cycle sums (role-major, 8 sections each)
+int mse_debug_timeline(unsigned long long *out24)
+{
+    unsigned long long zero[24] = {};
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(out24, HIP_SYMBOL(mse::g_timeline), sizeof(zero)) != hipSuccess) return -1;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(mse::g_timeline), zero, sizeof(zero)) != hipSuccess) return -1;
+    return 0;
+}
+#endif
 
 const char *mse_last_error(void) { return g_last_error.c_str(); }
 
@@ -1293,14 +1363,21 @@ int mse_create_indexed(mse_env **out, const mse_config *cfg, int64_t n_envs, int
                 worst = sum > worst ? sum : worst;
             }
         }
-        const bool fits = worst <= kRingMaxPerStep && !h->literal;
+        // ... and its LDS image (ring, obs tile, two snapshots, bale ledger, tables) within the CU's 160 KiB
+        size_t ring_lds = (size_t)P.table_words * 4u;
+        const bool nz = h->noise_on;
+        if (cfg->env_kind == MSE_ENV_SORT) ring_lds += nz ? RingLayout<1, true>::table_offset : RingLayout<1, false>::table_offset;
+        else if (cfg->env_kind == MSE_ENV_PRESS) ring_lds += nz ? RingLayout<2, true>::table_offset : RingLayout<2, false>::table_offset;
+        else ring_lds += nz ? RingLayout<3, true>::table_offset : RingLayout<3, false>::table_offset;
+        P.ring_worst = worst;
+        const bool fits = worst <= kRingMaxPerStep && !h->literal && ring_lds <= (size_t)160 * 1024;
         h->ring = h->pipelined && fits && cfg->rollout_pipeline != 1;
         if (cfg->rollout_pipeline == 3 && !fits) {
             (void)hipFree(h->planes);
             (void)hipFree(h->err_count);
             delete h;
-            return fail(MSE_ERR_UNSUPPORTED_CONFIG, "rollout_pipeline=3 (ring kernel) needs at most 31 draws per step "
-                                                    "and the integer draw path");
+            return fail(MSE_ERR_UNSUPPORTED_CONFIG, "rollout_pipeline=3 (ring kernel) needs at most 31 draws per step, "
+                                                    "the integer draw path and an LDS image within 160 KiB");
         }
     }
 

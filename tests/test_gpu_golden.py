@@ -20,14 +20,15 @@ ALWAYS_SKIP_WORDS = [4, 5, 10, 11]
 
 
 class GpuDriver:
-    def __init__(self, meta, literal_choice=False):
+    def __init__(self, meta, literal_choice=False, library=None):
         import torch
         import marl_sortingenv_amd as M
 
         self.torch = torch
         self.env = M.BatchedSortingEnv(kind=meta["kind"], num_envs=1, device=0, base_seed=meta["ctor_seed"],
                                        max_steps=meta["max_steps"], noise_sorting=meta["noise_sorting"],
-                                       balesize=meta["balesize"], auto_reset=False, literal_choice=literal_choice)
+                                       balesize=meta["balesize"], auto_reset=False, literal_choice=literal_choice,
+                                       library=library)
         self.prev_acc = None
         self.acc_sorter = None
 

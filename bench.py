@@ -190,7 +190,8 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS, "traffic": measured_traffic(args, n, chunk),
-                "kernel": "k_rollout_ring" if n <= 131072 else "k_rollout", "launch_ms": per_launch_ms,
+                "kernel": ("k_sample + k_step" if args.mode == "step" else
+                           "k_rollout_ring" if n <= 131072 else "k_rollout"), "launch_ms": per_launch_ms,
                 "algorithmic_bytes_per_env_step": bytes_per_step, "env_steps_per_launch": n * chunk,
             },
         }

@@ -89,6 +89,8 @@ def main():
     ap.add_argument("--no-outputs", action="store_true", help="diagnostic only: skip obs/mask writes (INVALID as a result)")
     ap.add_argument("--mode", default="rollout", choices=["rollout", "step"],
                     help="rollout: fused mse_rollout launches (headline); step: mse_sample_actions + mse_step per step")
+    ap.add_argument("--pipeline", type=int, default=0, choices=[0, 1, 2, 3],
+                    help="mse_config.rollout_pipeline: 0 by size (default), 1 two-role, 2 one lane per env, 3 three-role ring")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
     args = ap.parse_args()
@@ -101,18 +103,25 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    n_dev = torch.cuda.device_count()
+    # one rank per GPU over RCCL; with fewer GPUs than ranks (a rehearsal of the N > 1 path on a one-GPU box) the
+    # ranks share devices and the two scalar collectives of this script go over gloo
+    dev_index = (local_rank % max(1, n_dev)) if world > 1 else 0
+    rehearsal = world > 1 and n_dev < world
+    torch.cuda.set_device(dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-    else:
-        torch.cuda.set_device(0)
+        if rehearsal:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index))
     assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    dev = torch.device("cuda", dev_index)
 
     n = args.envs
     env = M.BatchedSortingEnv(kind=args.kind, num_envs=n, device=dev, base_seed=0, index_offset=rank * n,
-                              max_steps=args.max_steps, noise_sorting=args.noise, balesize=200, auto_reset=True)
+                              max_steps=args.max_steps, noise_sorting=args.noise, balesize=200, auto_reset=True,
+                              rollout_pipeline=args.pipeline)
     chunk = max(1, args.chunk)
     buf = env.alloc_rollout(chunk, obs=not args.no_outputs, mask=not args.no_outputs)
     stream = torch.cuda.current_stream(dev)
@@ -154,7 +163,7 @@ def main():
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
@@ -185,13 +194,16 @@ def main():
                 "balesize": 200, "noise_sorting": args.noise, "policy": "on-device masked-uniform, seed 2024",
                 "steps_per_launch": chunk, "outputs": "none (diagnostic)" if args.no_outputs else
                 "obs f32[K,N,D], mask u8[K,N,A], action i32, reward f32, done u8 per step",
-                "parallelism": f"env-index sharding x{world}, no data-path collective",
+                "parallelism": f"env-index sharding x{world}, no data-path collective" +
+                               (f" (REHEARSAL: {world} ranks on {n_dev} GPU)" if rehearsal else ""),
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS, "traffic": measured_traffic(args, n, chunk),
                 "kernel": ("k_sample + k_step" if args.mode == "step" else
-                           "k_rollout_ring" if n <= 131072 else "k_rollout"), "launch_ms": per_launch_ms,
+                           {1: "k_rollout_po", 2: "k_rollout", 3: "k_rollout_ring"}.get(
+                               args.pipeline, "k_rollout_ring" if n <= 131072 else "k_rollout")),
+                "launch_ms": per_launch_ms,
                 "algorithmic_bytes_per_env_step": bytes_per_step, "env_steps_per_launch": n * chunk,
             },
         }

@@ -77,7 +77,7 @@ struct Params {
     int sev_negative, mild_negative; // overflow_penalty_severe / _mild < 0 (then that bracket returns early)
     int k_thr[4];           // hundredths of python round(quality_threshold, 2): purity of an empty container
     // offsets (in 4-byte words) into the table image; see build_tables
-    int off_lvl, off_pdiff, off_timer0, off_timer1, off_tanh, off_eff, off_pat, off_acc, off_bonus, off_ptime, off_cst, off_jump, table_words;
+    int off_lvl, off_pdiff, off_timer0, off_timer1, off_tanh, off_eff, off_pat, off_acc, off_bonus, off_ptime, off_cst, off_jump, off_back, table_words;
     int ring_worst; // most sort_material draws one step can make with this config (k_rollout_ring flow control)
 };
 
@@ -294,7 +294,7 @@ __device__ __forceinline__ int select_kth_bit(uint32_t bits, int k)
 // Diagnostic build only (-DMSE_TIMELINE, tools/timeline.py): s_memtime deltas per section and role, summed
 // into a device symbol by lane 0 of every wave.  The shipped library compiles none of this.
 #ifdef MSE_TIMELINE
-__device__ unsigned long long g_timeline[3 * 8];
+__device__ unsigned long long g_timeline[4 * 8]; // [3]: launch edges seen by the dynamics wave
 struct Timeline {
     unsigned long long last;
     unsigned long long acc[8];
@@ -356,19 +356,39 @@ __device__ __forceinline__ uint32_t stage_word(int id, const Params &P)
     return id == 0 ? P.pat_word[0] : (id == 1 ? P.pat_word[1] : P.pat_word[2]);
 }
 
+// The state planes of one env as loaded, before unpacking: a kernel that has something to do while the loads
+// fly (k_rollout_ring copies the table image) issues load_env_raw first and unpacks afterwards.
+struct EnvRaw {
+    uint4 a, b, c0, c1, t, f, m0, m1, m2, ns, nq, ps, pq;
+};
+
 template <int KIND, bool NOISE>
-__device__ __forceinline__ void load_env(Env &e, const uint4 *__restrict__ planes, const Params &P, long long i)
+__device__ __forceinline__ void load_env_raw(EnvRaw &r, const uint4 *__restrict__ planes, const Params &P, long long i)
 {
     const long long n_pad = P.n_pad;
-    uint4 a = planes[PL_RNG_STATE * n_pad + i];
-    uint4 b = planes[PL_RNG_INC * n_pad + i];
-    uint4 c0 = planes[PL_ACC01 * n_pad + i];
-    uint4 c1 = planes[PL_ACC23 * n_pad + i];
-    uint4 t = planes[PL_CONT_TRUE * n_pad + i];
-    uint4 f = planes[PL_CONT_FALSE * n_pad + i];
-    uint4 m0 = planes[PL_MISC0 * n_pad + i];
-    uint4 m1 = planes[PL_MISC1 * n_pad + i];
-    uint4 m2 = planes[PL_MISC2 * n_pad + i];
+    r.a = planes[PL_RNG_STATE * n_pad + i];
+    r.b = planes[PL_RNG_INC * n_pad + i];
+    r.c0 = planes[PL_ACC01 * n_pad + i];
+    r.c1 = planes[PL_ACC23 * n_pad + i];
+    r.t = planes[PL_CONT_TRUE * n_pad + i];
+    r.f = planes[PL_CONT_FALSE * n_pad + i];
+    r.m0 = planes[PL_MISC0 * n_pad + i];
+    r.m1 = planes[PL_MISC1 * n_pad + i];
+    r.m2 = planes[PL_MISC2 * n_pad + i];
+    if (NOISE) {
+        r.ns = planes[PL_NOISE_STATE * n_pad + i];
+        r.nq = planes[PL_NOISE_INC * n_pad + i];
+    }
+    if (KIND == 1) {
+        r.ps = planes[PL_PRESS_STATE * n_pad + i];
+        r.pq = planes[PL_PRESS_INC * n_pad + i];
+    }
+}
+
+template <int KIND, bool NOISE>
+__device__ __forceinline__ void unpack_env(Env &e, const EnvRaw &r, const Params &P)
+{
+    const uint4 a = r.a, b = r.b, c0 = r.c0, c1 = r.c1, t = r.t, f = r.f, m0 = r.m0, m1 = r.m1, m2 = r.m2;
     e.rng.s_lo = (uint64_t)a.x | ((uint64_t)a.y << 32);
     e.rng.s_hi = (uint64_t)a.z | ((uint64_t)a.w << 32);
     e.rng.i_lo = (uint64_t)b.x | ((uint64_t)b.y << 32);
@@ -400,21 +420,27 @@ __device__ __forceinline__ void load_env(Env &e, const uint4 *__restrict__ plane
     e.episode = m2.z;
     e.press_uint = m2.w;
     if (NOISE) {
-        uint4 s = planes[PL_NOISE_STATE * n_pad + i];
-        uint4 q = planes[PL_NOISE_INC * n_pad + i];
+        const uint4 s = r.ns, q = r.nq;
         e.noise.s_lo = (uint64_t)s.x | ((uint64_t)s.y << 32);
         e.noise.s_hi = (uint64_t)s.z | ((uint64_t)s.w << 32);
         e.noise.i_lo = (uint64_t)q.x | ((uint64_t)q.y << 32);
         e.noise.i_hi = (uint64_t)q.z | ((uint64_t)q.w << 32);
     }
     if (KIND == 1) {
-        uint4 s = planes[PL_PRESS_STATE * n_pad + i];
-        uint4 q = planes[PL_PRESS_INC * n_pad + i];
+        const uint4 s = r.ps, q = r.pq;
         e.press.s_lo = (uint64_t)s.x | ((uint64_t)s.y << 32);
         e.press.s_hi = (uint64_t)s.z | ((uint64_t)s.w << 32);
         e.press.i_lo = (uint64_t)q.x | ((uint64_t)q.y << 32);
         e.press.i_hi = (uint64_t)q.z | ((uint64_t)q.w << 32);
     }
+}
+
+template <int KIND, bool NOISE>
+__device__ __forceinline__ void load_env(Env &e, const uint4 *__restrict__ planes, const Params &P, long long i)
+{
+    EnvRaw r;
+    load_env_raw<KIND, NOISE>(r, planes, P, i);
+    unpack_env<KIND, NOISE>(e, r, P);
 }
 
 __device__ __forceinline__ uint4 pack_u64x2(uint64_t lo, uint64_t hi)
@@ -431,10 +457,10 @@ __device__ __forceinline__ uint4 pack_f64x2(double a, double b)
 // write_inc: the increments only change on a seeded reset
 template <int KIND, bool NOISE>
 __device__ __forceinline__ void store_env(const Env &e, uint4 *__restrict__ planes, const Params &P, long long i,
-                                          bool write_inc)
+                                          bool write_inc, bool write_rng_state = true)
 {
     const long long n_pad = P.n_pad;
-    planes[PL_RNG_STATE * n_pad + i] = pack_u64x2(e.rng.s_lo, e.rng.s_hi);
+    if (write_rng_state) planes[PL_RNG_STATE * n_pad + i] = pack_u64x2(e.rng.s_lo, e.rng.s_hi);
     if (write_inc) planes[PL_RNG_INC * n_pad + i] = pack_u64x2(e.rng.i_lo, e.rng.i_hi);
     planes[PL_ACC01 * n_pad + i] = pack_f64x2(e.acc[0], e.acc[1]);
     planes[PL_ACC23 * n_pad + i] = pack_f64x2(e.acc[2], e.acc[3]);
@@ -620,6 +646,22 @@ __device__ __forceinline__ void pcg_jump(Pcg &g, uint32_t n, const uint64_t *jum
             g.s_lo = lo;
         }
     }
+}
+
+// s_{n-d} = A_{-d} s_n + G_{-d} inc  with  A_{-d} = M^{-d},  G_{-d} = -M^{-d} (1 + M + ... + M^{d-1})  (mod 2^128):
+// one table entry per d = 0..32, so going back d <= 32 steps is two 128-bit multiplies whatever d is.  The RNG waves
+// of k_rollout_ring end a launch at most 64 (usually < `worst`) outputs ahead of what the env consumed and hand the
+// stream back this way.
+constexpr int kRingBackSteps = 33;
+__device__ __forceinline__ void pcg_step_back(Pcg &g, uint32_t d, const uint64_t *back_tab)
+{
+    const uint64_t *t = back_tab + 4 * d; // d <= 32
+    uint64_t x_lo, x_hi, y_lo, y_hi;
+    mul128(t[0], t[1], g.s_lo, g.s_hi, x_lo, x_hi);
+    mul128(t[2], t[3], g.i_lo, g.i_hi, y_lo, y_hi);
+    const uint64_t lo = x_lo + y_lo;
+    g.s_hi = x_hi + y_hi + (lo < x_lo ? 1ull : 0ull);
+    g.s_lo = lo;
 }
 
 // the lane advances the env's own generator
@@ -1068,6 +1110,7 @@ struct Tables {
     // the step loop (SGPR pressure), each fetch a scalar-cache round trip
     const double *cst;     // [CST_COUNT], see enum Cst
     const uint64_t *jump;  // [kJumpBits][4] LCG jump-ahead (pcg_jump)
+    const uint64_t *back;  // [kRingBackSteps][4] LCG jump BACK by d = 0..31 steps (pcg_step_back)
 };
 
 __device__ __forceinline__ Tables tables_at(const uint32_t *base, const Params &P)
@@ -1085,6 +1128,7 @@ __device__ __forceinline__ Tables tables_at(const uint32_t *base, const Params &
     t.press_time = reinterpret_cast<const int *>(base + P.off_ptime);
     t.cst = reinterpret_cast<const double *>(base + P.off_cst);
     t.jump = reinterpret_cast<const uint64_t *>(base + P.off_jump);
+    t.back = reinterpret_cast<const uint64_t *>(base + P.off_back);
     return t;
 }
 

@@ -42,9 +42,41 @@ __device__ __forceinline__ void lds_barrier_all()
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+// Table image -> LDS in 16-byte pieces, every load of a thread issued before its first LDS write (a word-by-word
+// loop is one global round trip per iteration: 12 of them with 256 threads).  issue() / commit() are separate so a
+// kernel can put other loads in flight between them.  `words` is a multiple of 4 (build_tables pads).
+template <int THREADS, int U>
+struct TableCopy {
+    uint4 x[U];
+    __device__ __forceinline__ void issue(const uint32_t *__restrict__ src, int words, int t)
+    {
+        const uint4 *s4 = reinterpret_cast<const uint4 *>(src);
+        const int n4 = words >> 2;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int idx = u * THREADS + t;
+            if (idx < n4) x[u] = s4[idx];
+        }
+    }
+    __device__ __forceinline__ void commit(uint32_t *dst, const uint32_t *__restrict__ src, int words, int t) const
+    {
+        uint4 *d4 = reinterpret_cast<uint4 *>(dst);
+        const uint4 *s4 = reinterpret_cast<const uint4 *>(src);
+        const int n4 = words >> 2;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int idx = u * THREADS + t;
+            if (idx < n4) d4[idx] = x[u];
+        }
+        for (int idx = U * THREADS + t; idx < n4; idx += THREADS) d4[idx] = s4[idx]; // larger images than U pieces
+    }
+};
+
 __device__ __forceinline__ void load_tables_to_lds(uint32_t *dst, const uint32_t *__restrict__ src, int words, int tid)
 {
-    for (int w = tid; w < words; w += kBlock) dst[w] = src[w];
+    TableCopy<kBlock, 4> tc;
+    tc.issue(src, words, tid);
+    tc.commit(dst, src, words, tid);
     __syncthreads();
 }
 
@@ -337,7 +369,11 @@ __global__ __launch_bounds__(kPoThreads) void k_rollout_po(Params P, uint4 *__re
     const long long i = row0 + el;                   // < n_pad always (planes are padded to 256 envs)
     const bool live = i < P.n;
 
-    for (int w = tid; w < P.table_words; w += kPoThreads) ltab[w] = table_image[w];
+    {
+        TableCopy<kPoThreads, 2> tc;
+        tc.issue(table_image, P.table_words, tid);
+        tc.commit(ltab, table_image, P.table_words, tid);
+    }
     __syncthreads();
     const Tables tb = tables_at(ltab, P);
 
@@ -516,10 +552,29 @@ __global__ __launch_bounds__(kRingThreads) void k_rollout_ring(Params P, uint4 *
     const long long row0 = (long long)blockIdx.x * kPoEnvs;
     const long long i = row0 + el;                   // < n_pad always
     const bool live = i < P.n;
+#ifdef MSE_TIMELINE
+    Timeline edge;
+    edge.start();
+#endif
 
-    for (int w = tid; w < P.table_words; w += kRingThreads) ltab[w] = table_image[w];
-    __syncthreads();
+    // Launch prologue, overlapped: the RNG waves start priming the ring at once (they never read a table before
+    // the end of the launch); the dynamics waves issue their state loads and, with the observers, copy the table
+    // image to LDS while those fly.  B_init is the first barrier: it publishes tables and ring together.
     const Tables tb = tables_at(ltab, P);
+    Env e;
+    EnvRaw raw;
+    int sm = -1;
+    if (role == 0 && live) {
+        load_env_raw<KIND, NOISE>(raw, planes, P, i);
+        if (KIND == 2 && sort_mode != nullptr) sm = sort_mode[i];
+    }
+    if (role != 2) {
+        TableCopy<2 * kPoEnvs, 2> tc;
+        tc.issue(table_image, P.table_words, tid);
+        tc.commit(ltab, table_image, P.table_words, tid);
+    }
+    if (role == 0 && live) unpack_env<KIND, NOISE>(e, raw, P);
+    MSE_TL(edge, 0); // state loads and the table image -> LDS
 
     if (role == 2) {
         // ------------------------------------------------------------------ RNG waves
@@ -574,6 +629,17 @@ __global__ __launch_bounds__(kRingThreads) void k_rollout_ring(Params P, uint4 *
             need = live ? r + worst * (steps_left < 2u ? steps_left : 2u) : 0u;
             cap = live ? r + (ahead < (uint32_t)kRingDepth ? ahead : (uint32_t)kRingDepth) : 0u;
         }
+        // hand the stream back: this lane stands d <= worst outputs past what the env consumed (nothing is
+        // produced after the last barrier, and before it at most `worst` per remaining step)
+        if (live) {
+            uint32_t d = w - lpos[el]; // <= 64, the ring's depth
+            if (__builtin_expect(d > 32u, 0)) { // only after steps that drew nothing (an episode's first two)
+                pcg_step_back(g, 32u, tb.back);
+                d -= 32u;
+            }
+            pcg_step_back(g, d, tb.back);
+            planes[PL_RNG_STATE * P.n_pad + i] = pack_u64x2(g.s_lo, g.s_hi);
+        }
 #ifdef MSE_TIMELINE
         tl.flush(2);
 #endif
@@ -586,12 +652,6 @@ __global__ __launch_bounds__(kRingThreads) void k_rollout_ring(Params P, uint4 *
         if (P.track_bales) {
 #pragma unroll
             for (int m = 0; m < 5; ++m) lbale[m * kPoEnvs + el] = planes[(long long)(PL_BALE0 + m) * P.n_pad + i];
-        }
-        Env e;
-        int sm = -1;
-        if (live) {
-            load_env<KIND, NOISE>(e, planes, P, i);
-            if (KIND == 2 && sort_mode != nullptr) sm = sort_mode[i];
         }
         __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): no load is outstanding inside the step loop
         RngRing rng;
@@ -608,7 +668,9 @@ __global__ __launch_bounds__(kRingThreads) void k_rollout_ring(Params P, uint4 *
         rng.f_max = 0u;
         uint32_t cur_mask = live ? action_mask_bits<KIND>(e, P) : 1u;
         lpos[el] = 0;
+        MSE_TL(edge, 1); // state load
         lds_barrier_all(); // B_init
+        MSE_TL(edge, 2); // waiting for the ring to be primed
 #ifdef MSE_TIMELINE
         e.tl.start();
 #endif
@@ -651,14 +713,19 @@ __global__ __launch_bounds__(kRingThreads) void k_rollout_ring(Params P, uint4 *
 #ifdef MSE_TIMELINE
         e.tl.flush(0);
 #endif
+        MSE_TL(edge, 3); // the step loop
         if (live) {
-            pcg_jump(e.rng, rng.pos(), tb.jump); // the stream position after everything this launch consumed
-            store_env<KIND, NOISE>(e, planes, P, i, false);
+            // the generator state is written by the RNG lane (it steps back to the consumed position)
+            store_env<KIND, NOISE>(e, planes, P, i, false, /*write_rng_state=*/false);
         }
         if (P.track_bales) {
 #pragma unroll
             for (int m = 0; m < 5; ++m) planes[(long long)(PL_BALE0 + m) * P.n_pad + i] = lbale[m * kPoEnvs + el];
         }
+        MSE_TL(edge, 5); // state stores issued
+#ifdef MSE_TIMELINE
+        edge.flush(3);
+#endif
     } else {
         // ------------------------------------------------------------------ observer waves
         long long rem = P.n - row0;
@@ -1117,6 +1184,27 @@ static int build_tables(const mse_config &c, Params &P, std::vector<uint32_t> &i
             A = A * A;
         }
     }
+    P.off_back = (int)image.size(); // even
+    {
+        // jump back by d steps (pcg_step_back): A_{-d} = M^{-d}, G_{-d} = -M^{-d} G_d
+        typedef unsigned __int128 u128;
+        const u128 M = (((u128)0x2360ED051FC65DA4ull) << 64) | (u128)0x4385DF649FCCF645ull;
+        u128 Minv = M; // Newton: x <- x (2 - M x) doubles the correct low bits; M * M = 1 mod 8 gives 3 to start
+        for (int it = 0; it < 7; ++it) Minv = Minv * (2 - M * Minv);
+        u128 Ainv = 1, Gd = 0, Ad = 1; // d = 0
+        for (int d = 0; d < kRingBackSteps; ++d) {
+            const u128 Gneg = (u128)0 - Ainv * Gd;
+            const uint64_t w4[4] = {(uint64_t)Ainv, (uint64_t)(Ainv >> 64), (uint64_t)Gneg, (uint64_t)(Gneg >> 64)};
+            for (int q = 0; q < 4; ++q) {
+                image.push_back((uint32_t)w4[q]);
+                image.push_back((uint32_t)(w4[q] >> 32));
+            }
+            Gd = Gd + Ad; // G_{d+1} = G_d + M^d
+            Ad = Ad * M;
+            Ainv = Ainv * Minv;
+        }
+    }
+    while (image.size() & 3u) image.push_back(0u); // copied to LDS in 16-byte pieces
     P.table_words = (int)image.size();
     if (P.table_words > 16384) {
         why = "container_capacity / bale_standard_size too large for the LDS-resident tables (64 KiB)";
@@ -1210,11 +1298,11 @@ int mse_version(void) { return MSE_VERSION; }
 uint32_t mse_tie_window(void) { return MSE_TIE_WINDOW; }
 #ifdef MSE_TIMELINE
 // diagnostic build: read and clear the per-role section cycle sums (role-major, 8 sections each)
-int mse_debug_timeline(unsigned long long *out24)
+int mse_debug_timeline(unsigned long long *out32)
 {
-    unsigned long long zero[24] = {};
+    unsigned long long zero[32] = {};
     if (hipDeviceSynchronize() != hipSuccess) return -1;
-    if (hipMemcpyFromSymbol(out24, HIP_SYMBOL(mse::g_timeline), sizeof(zero)) != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(out32, HIP_SYMBOL(mse::g_timeline), sizeof(zero)) != hipSuccess) return -1;
     if (hipMemcpyToSymbol(HIP_SYMBOL(mse::g_timeline), zero, sizeof(zero)) != hipSuccess) return -1;
     return 0;
 }

@@ -23,8 +23,8 @@ env = M.BatchedSortingEnv(kind=kind, num_envs=n, device=0, base_seed=0, max_step
                           balesize=200, library=lib)
 buf = env.alloc_rollout(K)
 L = env.L
-L.mse_debug_timeline.argtypes = [C.POINTER(C.c_uint64 * 24)]
-out = (C.c_uint64 * 24)()
+L.mse_debug_timeline.argtypes = [C.POINTER(C.c_uint64 * 32)]
+out = (C.c_uint64 * 32)()
 for _ in range(2):
     env.rollout(K, buffers=buf)
 L.mse_debug_timeline(C.byref(out))  # clear the warm-up
@@ -43,6 +43,9 @@ names = {
     2: ["produce", "barrier wait", "", "", "", "", "", ""],
 }
 print(f"{kind} {n} envs: {ms * 1e3:.1f} us per launch of {K} steps = {ms * 1e3 / K:.2f} us/step (instrumented build)")
+ev = [out[24 + k] / (4 * launches) for k in range(6)]
+print("  launch edges (dynamics wave, ticks per launch): " + ", ".join(
+    f"{nm} {v:.0f}" for nm, v in zip(["tables->LDS", "state load", "ring priming wait", "step loop", "jump-ahead", "state store"], ev)))
 for role, label in ((0, "dynamics"), (1, "observer"), (2, "rng")):
     vals = [out[role * 8 + k] / (waves * launches * K) for k in range(8)]
     tot = sum(vals)

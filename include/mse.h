@@ -193,6 +193,24 @@ int mse_algorithmic_bytes_per_step(const mse_env *env);
  * library; the test-only build libmse_hip_widetie.so reports 0x08000000. */
 uint32_t mse_tie_window(void);
 
+/* ---- the policy on the caller's side of step() -----------------------------------------------
+ * Batched forward of the reference's actor-critic MLP (src/training.py:115: net_arch=dict(pi=[32,32], vf=[32,32]),
+ * tanh; MaskableActorCriticPolicy) with masked categorical sampling, on the f32 matrix cores.
+ * weights_host: mse_policy_num_weights(D, A) floats, torch.nn.Linear layout ([out, in] row-major), in this order:
+ *   pi_w1[32*D] pi_b1[32] pi_w2[32*32] pi_b2[32] act_w[A*32] act_b[A]   (mlp_extractor.policy_net.0/.2, action_net)
+ *   vf_w1[32*D] vf_b1[32] vf_w2[32*32] vf_b2[32] val_w[32]   val_b[1]   (mlp_extractor.value_net.0/.2, value_net)
+ * mse_policy_forward: obs_dev f32[N, D]; mask_dev u8[N, A] or NULL (invalid actions get logit -1e8, as
+ * sb3_contrib's MaskableCategorical); deterministic != 0: argmax, else inverse-cdf sampling with the engine's
+ * counter-based stream (seed, global env index = index_offset + i, t).  Outputs (each may be NULL):
+ * action i32[N], log-probability f32[N], value f32[N], masked logits f32[N, A]. */
+typedef struct mse_policy mse_policy;
+int64_t mse_policy_num_weights(int obs_dim, int n_actions);
+int mse_policy_create(mse_policy **out, int obs_dim, int n_actions, const float *weights_host, int device_id);
+int mse_policy_destroy(mse_policy *policy);
+int mse_policy_forward(mse_policy *policy, int64_t n, int64_t index_offset, const float *obs_dev, const uint8_t *mask_dev,
+                       uint64_t seed, uint64_t t, int deterministic, int32_t *action_out, float *logp_out,
+                       float *value_out, float *logits_out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -15,6 +15,7 @@ EXPORTS = [
     "mse_create_indexed", "mse_destroy", "mse_num_envs", "mse_obs_dim", "mse_num_actions", "mse_reset",
     "mse_step", "mse_action_masks", "mse_rollout", "mse_sample_actions", "mse_rule_actions", "mse_get_state", "mse_set_state",
     "mse_error_count", "mse_algorithmic_bytes_per_step", "mse_tie_window",
+    "mse_policy_num_weights", "mse_policy_create", "mse_policy_destroy", "mse_policy_forward",
 ]
 
 _other_libs: dict = {}
@@ -97,6 +98,11 @@ def load_library(path: str | None = None) -> C.CDLL:
     for name in EXPORTS:
         getattr(L, name)  # AttributeError if the library does not export what include/mse.h declares
     L.mse_tie_window.restype = u32
+    L.mse_policy_num_weights.argtypes = [C.c_int, C.c_int]
+    L.mse_policy_num_weights.restype = i64
+    L.mse_policy_create.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.POINTER(C.c_float), C.c_int]
+    L.mse_policy_destroy.argtypes = [vp]
+    L.mse_policy_forward.argtypes = [vp, i64, i64, vp, vp, u64, u64, C.c_int, vp, vp, vp, vp, vp]
     if path is None:
         _lib = L
     else:

@@ -7,7 +7,7 @@ import subprocess
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 REPO_ROOT = os.path.dirname(PKG_DIR)
-SOURCES = [os.path.join(PKG_DIR, "csrc", "mse_lib.hip")]
+SOURCES = [os.path.join(PKG_DIR, "csrc", "mse_lib.hip"), os.path.join(PKG_DIR, "csrc", "mse_policy.hip")]
 HEADERS = [os.path.join(PKG_DIR, "csrc", "mse_device.h"), os.path.join(REPO_ROOT, "include", "mse.h")]
 LIB_PATH = os.environ.get("MSE_LIB_PATH") or os.path.join(PKG_DIR, "libmse_hip.so")  # override: experiments only
 

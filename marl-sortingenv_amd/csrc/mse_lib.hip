@@ -1309,6 +1309,9 @@ int mse_debug_timeline(unsigned long long *out32)
 #endif
 
 const char *mse_last_error(void) { return g_last_error.c_str(); }
+} // extern "C"
+int mse_internal_fail(int status, const char *msg) { return fail(status, msg); } // for the library's other translation units
+extern "C" {
 
 const char *mse_status_string(int status)
 {

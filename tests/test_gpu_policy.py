@@ -1,0 +1,151 @@
+"""PARITY (GPU): mse_policy_forward against a plain PyTorch fp32 restatement of the reference's policy
+(src/training.py:115-131: MaskableActorCriticPolicy, net_arch=dict(pi=[32,32], vf=[32,32]), tanh; sb3_contrib's
+MaskableCategorical: masked logits = -1e8, Categorical(logits=...)).
+
+Floating point, so tolerances (written here): logits / value 2e-5 absolute (MFMA sums in a permuted order, tanh by
+v_exp_f32 + v_rcp_f32), log-probabilities 1e-4.  stable_baselines3 is not installed in this image and the
+reference ships no policy fixture, so the network itself is "parity unpinned" beyond this torch reference of the
+same op; the weights are random with SB3's state_dict names and shapes."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+LOGIT_TOL, LOGP_TOL = 2e-5, 1e-4
+
+
+def _weights(obs_dim, n_actions, seed):
+    import torch
+
+    from marl_sortingenv_amd.policy import SB3_KEYS, _shapes
+
+    g = torch.Generator().manual_seed(seed)
+    return {k: (torch.randn(s, generator=g) * (0.5 if len(s) == 2 else 0.1)).float()
+            for k, s in zip(SB3_KEYS, _shapes(obs_dim, n_actions))}
+
+
+def _torch_reference(w, obs, mask):
+    """obs [N, D] f32 cpu, mask [N, A] bool cpu or None -> masked logits, log-softmax, value (all fp32, CPU)."""
+    import torch
+    import torch.nn.functional as F
+
+    hp = torch.tanh(F.linear(torch.tanh(F.linear(obs, w["mlp_extractor.policy_net.0.weight"],
+                                                 w["mlp_extractor.policy_net.0.bias"])),
+                             w["mlp_extractor.policy_net.2.weight"], w["mlp_extractor.policy_net.2.bias"]))
+    hv = torch.tanh(F.linear(torch.tanh(F.linear(obs, w["mlp_extractor.value_net.0.weight"],
+                                                 w["mlp_extractor.value_net.0.bias"])),
+                             w["mlp_extractor.value_net.2.weight"], w["mlp_extractor.value_net.2.bias"]))
+    logits = F.linear(hp, w["action_net.weight"], w["action_net.bias"])
+    if mask is not None:
+        logits = torch.where(mask, logits, torch.tensor(-1e8))
+    value = F.linear(hv, w["value_net.weight"], w["value_net.bias"]).squeeze(1)
+    return logits, torch.log_softmax(logits, dim=1), value
+
+
+def _word(seed, g, t):
+    """policy_word of csrc/mse_policy.hip (= the random policy's stream) on the host."""
+    M = 0xFFFFFFFF
+    x = (seed + g * 0x9E3779B1 + t * 0x85EBCA77) & M
+    x ^= ((seed >> 32) * 0x27D4EB2F) & M
+    x ^= x >> 16
+    x = (x * 0x85EBCA6B) & M
+    x ^= x >> 13
+    x = (x * 0xC2B2AE35) & M
+    x ^= x >> 16
+    return x
+
+
+@pytest.mark.parametrize("obs_dim,n_actions,n", [(29, 22, 1000), (16, 11, 333), (13, 2, 64), (29, 22, 31)])
+def test_policy_forward_matches_torch_fp32(obs_dim, n_actions, n):
+    import torch
+
+    import marl_sortingenv_amd as M
+
+    w = _weights(obs_dim, n_actions, seed=obs_dim * 100 + n_actions)
+    pol = M.MlpPolicy(obs_dim, n_actions, w, device=0)
+    g = torch.Generator().manual_seed(5)
+    obs = torch.rand((n, obs_dim), generator=g)  # observations live in [0, 1] (clip in env_super.py:339-359)
+    mask = torch.rand((n, n_actions), generator=g) < 0.6
+    mask[:, 0] = True  # action 0 is always valid in the reference's masks
+    for use_mask in (True, False):
+        mk = mask if use_mask else None
+        ref_logits, ref_logsm, ref_value = _torch_reference(w, obs, mk)
+        out = pol.forward(obs.cuda(), None if mk is None else mk.cuda(), seed=77, t=3, want_logits=True)
+        logits = out["logits"].cpu()
+        assert torch.allclose(logits, ref_logits, atol=LOGIT_TOL, rtol=1e-6), (logits - ref_logits).abs().max()
+        assert torch.allclose(out["value"].cpu(), ref_value, atol=LOGIT_TOL, rtol=1e-6)
+        act = out["action"].cpu().long()
+        assert bool(((act >= 0) & (act < n_actions)).all())
+        if mk is not None:
+            assert bool(mk.gather(1, act.unsqueeze(1)).all()), "a masked action was sampled"
+        # log-probability of the sampled action
+        assert torch.allclose(out["logp"].cpu(), ref_logsm.gather(1, act.unsqueeze(1)).squeeze(1), atol=LOGP_TOL)
+        # the sample is the inverse cdf of the engine's stream in action order: recompute it in fp64 from the
+        # device's own logits; a draw that lands within 1e-5 of a boundary may fall on either side
+        p = torch.softmax(logits.double(), dim=1).numpy()
+        cdf = np.cumsum(p, axis=1)
+        for i in range(n):
+            u = (_word(77, i, 3) >> 8) * 2.0 ** -24
+            k = int(np.searchsorted(cdf[i], u, side="right"))
+            k = min(k, n_actions - 1)
+            if int(act[i]) != k:
+                near = min(abs(u - cdf[i, j]) for j in range(n_actions))
+                assert near < 1e-5, (i, int(act[i]), k, u, cdf[i])
+        # deterministic = argmax of the masked logits
+        det = pol.forward(obs.cuda(), None if mk is None else mk.cuda(), deterministic=True)["action"].cpu().long()
+        top2 = torch.topk(ref_logits, 2, dim=1).values if n_actions > 1 else None
+        clear = (top2[:, 0] - top2[:, 1]) > 1e-4
+        assert bool((det[clear] == ref_logits.argmax(dim=1)[clear]).all())
+
+
+def test_policy_sampling_frequencies_follow_the_softmax():
+    """One observation, 20 000 steps of the stream: empirical action frequencies vs softmax probabilities."""
+    import torch
+
+    import marl_sortingenv_amd as M
+
+    obs_dim, n_actions, n = 29, 22, 20000
+    w = _weights(obs_dim, n_actions, seed=9)
+    pol = M.MlpPolicy(obs_dim, n_actions, w, device=0)
+    obs = torch.rand((1, obs_dim), generator=torch.Generator().manual_seed(1)).repeat(n, 1)
+    mask = torch.ones((n, n_actions), dtype=torch.bool)
+    mask[:, [3, 7, 20]] = False
+    out = pol.forward(obs.cuda(), mask.cuda(), seed=123, t=0)  # env index varies: n independent draws
+    freq = torch.bincount(out["action"].cpu().long(), minlength=n_actions).double() / n
+    _, logsm, _ = _torch_reference(w, obs[:1], mask[:1])
+    p = logsm.exp().double().squeeze(0)
+    assert float(freq[[3, 7, 20]].sum()) == 0.0
+    assert float((freq - p).abs().max()) < 4.0 * float((p * (1 - p) / n).sqrt().max()) + 1e-3
+
+
+def test_policy_drives_the_step_engine():
+    """policy.forward -> env.step loop stays on the device and only ever takes valid actions."""
+    import torch
+
+    import marl_sortingenv_amd as M
+
+    n = 4096
+    env = M.BatchedSortingEnv(kind="mono", num_envs=n, device=0, base_seed=3, max_steps=50, noise_sorting=0.0)
+    pol = M.MlpPolicy(env.obs_dim, env.num_actions, _weights(env.obs_dim, env.num_actions, seed=4), device=0)
+    obs, mask = env.obs, env.mask
+    total = torch.zeros((n,), dtype=torch.float64, device="cuda")
+    for t in range(60):
+        out = pol.forward(obs, mask, seed=11, t=t)
+        assert bool(torch.gather(mask, 1, out["action"].long().unsqueeze(1)).all())
+        obs, rew, done, mask = env.step(out["action"])
+        total += rew.double()
+    assert env.error_count() == 0 and bool(torch.isfinite(total).all())
+
+
+def test_policy_abi_errors():
+    import ctypes as C
+
+    import marl_sortingenv_amd as M
+
+    L = M.load_library()
+    h = C.c_void_p()
+    buf = (C.c_float * 8)()
+    assert L.mse_policy_create(C.byref(h), 64, 22, buf, 0) == -2  # MSE_ERR_UNSUPPORTED_CONFIG
+    assert L.mse_policy_create(C.byref(h), 29, 22, None, 0) == -1
+    assert b"mse_policy_create" in L.mse_last_error()
+    assert L.mse_policy_num_weights(29, 22) == 2 * (32 * 29 + 32 + 32 * 32 + 32) + 22 * 32 + 22 + 32 + 1

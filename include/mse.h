@@ -155,6 +155,12 @@ int mse_step(mse_env *env, const int32_t *action_dev, const int32_t *sort_mode_d
  * env_2_press.py:66-67 -> env_super.py:869-885, env_1_sort.py:74-76). mask_out u8[N, A]. */
 int mse_action_masks(mse_env *env, uint8_t *mask_out, void *stream);
 
+/* The observation Env_2_Pressing.step hands its sorting agent (env_2_press.py:95-104: get_sort_obs() after the
+ * coming step's flow update, before the sensor setting), for every env: obs13_out f32[N, 13].  A preview - the
+ * state is not changed; feed the agent's decisions to the next mse_step / mse_rollout as sort_mode_dev.
+ * Defined for every env kind (the sorting view of the state one flow update ahead). */
+int mse_sort_agent_obs(mse_env *env, float *obs13_out, void *stream);
+
 /* K fused steps with the on-device masked-uniform random policy (the reference's
  * mode='random' with masking, env_monolith.py:152-158, with a counter-based policy stream
  * instead of the global np.random).  State stays in registers across the K steps.

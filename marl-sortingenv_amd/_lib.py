@@ -15,7 +15,7 @@ EXPORTS = [
     "mse_create_indexed", "mse_destroy", "mse_num_envs", "mse_obs_dim", "mse_num_actions", "mse_reset",
     "mse_step", "mse_action_masks", "mse_rollout", "mse_sample_actions", "mse_rule_actions", "mse_get_state", "mse_set_state",
     "mse_error_count", "mse_algorithmic_bytes_per_step", "mse_tie_window",
-    "mse_policy_num_weights", "mse_policy_create", "mse_policy_destroy", "mse_policy_forward",
+    "mse_sort_agent_obs", "mse_policy_num_weights", "mse_policy_create", "mse_policy_destroy", "mse_policy_forward",
 ]
 
 _other_libs: dict = {}
@@ -88,6 +88,7 @@ def load_library(path: str | None = None) -> C.CDLL:
     L.mse_reset.argtypes = [vp, vp, vp, vp, vp, vp]
     L.mse_step.argtypes = [vp, vp, vp, u32, vp, vp, vp, vp, vp, vp, vp]
     L.mse_action_masks.argtypes = [vp, vp, vp]
+    L.mse_sort_agent_obs.argtypes = [vp, vp, vp]
     L.mse_rollout.argtypes = [vp, i32, u64, vp, u32, vp, vp, vp, vp, vp, vp]
     L.mse_sample_actions.argtypes = [vp, u64, vp, vp]
     L.mse_rule_actions.argtypes = [vp, vp, vp]

@@ -124,6 +124,14 @@ class BatchedSortingEnv:
             check(self.L.mse_action_masks(self._h, _ptr(out), self._stream()))
         return out
 
+    def sort_agent_obs(self) -> torch.Tensor:
+        """f32[N, 13]: what Env_2_Pressing.step hands its sorting agent on the coming step (env_2_press.py:101):
+        get_sort_obs() after that step's flow update.  Feed the agent's decisions back as step(..., sort_mode=)."""
+        out = torch.empty((self.num_envs, 13), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            check(self.L.mse_sort_agent_obs(self._h, _ptr(out), self._stream()))
+        return out
+
     def sample_actions(self, policy_seed: int = 2024) -> torch.Tensor:
         out = torch.empty((self.num_envs,), dtype=torch.int32, device=self.device)
         with torch.cuda.device(self.device):

@@ -868,6 +868,27 @@ __global__ __launch_bounds__(kBlock) void k_masks(Params P, const uint4 *__restr
     for (int j = 0; j < A; ++j) mask_out[i * A + j] = (uint8_t)((bits >> j) & 1u);
 }
 
+// What Env_2_Pressing.step hands its sorting agent (env_2_press.py:95-104): get_sort_obs() after the coming
+// step's flow update and before the sensor is set.  A preview of state the step will recompute: nothing is stored
+// (the flow update is a function of the state; the occupancy draw it discards comes from a stream nobody observes).
+__global__ __launch_bounds__(kBlock) void k_sort_agent_obs(Params P, const uint4 *__restrict__ planes,
+                                                           const uint32_t *__restrict__ table_image,
+                                                           float *__restrict__ obs_out)
+{
+    const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= P.n) return;
+    const Tables tb = tables_at(table_image, P); // cold kernel: tables straight from global memory
+    Env e;
+    load_env<2, false>(e, planes, P, i);
+    update_environment(e);
+    int k[4];
+    container_purity_k(e, k);
+    float o[13];
+    sort_obs(e, P, tb, k, o);
+#pragma unroll
+    for (int j = 0; j < 13; ++j) obs_out[i * 13 + j] = o[j];
+}
+
 template <int KIND>
 __global__ __launch_bounds__(kBlock) void k_sample(Params P, const uint4 *__restrict__ planes,
                                                    const uint32_t *__restrict__ table_image, uint32_t flags,
@@ -1627,6 +1648,15 @@ int mse_action_masks(mse_env *h, uint8_t *mask_out, void *stream)
     case 2: hipLaunchKernelGGL(k_masks<2>, grid_of(h), dim3(kBlock), 0, s, h->P, h->planes, mask_out); break;
     default: hipLaunchKernelGGL(k_masks<3>, grid_of(h), dim3(kBlock), 0, s, h->P, h->planes, mask_out); break;
     }
+    MSE_CHECK_LAUNCH();
+    return MSE_OK;
+}
+
+int mse_sort_agent_obs(mse_env *h, float *obs13_out, void *stream)
+{
+    if (!h || !obs13_out) return fail(MSE_ERR_INVALID_ARGUMENT, "env/obs13_out is NULL");
+    hipLaunchKernelGGL(k_sort_agent_obs, grid_of(h), dim3(kBlock), 0, static_cast<hipStream_t>(stream), h->P, h->planes,
+                       h->tables, obs13_out);
     MSE_CHECK_LAUNCH();
     return MSE_OK;
 }

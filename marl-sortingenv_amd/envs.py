@@ -173,10 +173,10 @@ class Env_2_Pressing(_SingleEnv):
     def step(self, action, use_action_masking=True, check_overflow=False):
         sort_mode = None
         if self.sort_agent is not None:
-            # the agent sees the sorting observation AFTER this step's material flow (env_2_press.py:101);
-            # that pre-action view is not materialised by the fused step, so agents that look at their
-            # observation need the batched API (sort_mode tensor); predict() is called with the last obs.
-            sort_mode, _ = self.sort_agent.predict(self.get_obs(), deterministic=True)
+            # the agent sees get_sort_obs() AFTER this step's material flow (env_2_press.py:101-104):
+            # mse_sort_agent_obs previews exactly that view of the coming step
+            sort_obs = self._batched.sort_agent_obs()[0].cpu().numpy()
+            sort_mode, _ = self.sort_agent.predict(sort_obs, deterministic=True)
             sort_mode = int(sort_mode)
         obs, reward, terminated, truncated = self._step(action, sort_mode, use_action_masking, check_overflow)
         return obs, reward, terminated, truncated, {"action": int(action)}

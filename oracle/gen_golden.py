@@ -110,6 +110,7 @@ def run_scenario(sc):
     A = env.action_space.n
     rows = {k: [] for k in ("op", "arg", "sort_mode", "flags", "obs", "reward", "terminated", "mask",
                             "ints", "dbls", "rng")}
+    agent_obs = []  # press only: the observation Env_2.step gave its sorting agent (env_2_press.py:101-104)
 
     def record(op, arg, sm, flags, obs, rew, term):
         I, Dd, R = ref_harness.snapshot(env)
@@ -129,6 +130,7 @@ def run_scenario(sc):
     for seed in seeds:
         obs, _ = env.reset(seed=seed)
         record(1, seed, -1, 0, obs, 0.0, 0)
+        agent_obs.append(np.zeros(13, dtype=np.float32))
         for t in range(seg):
             a, sm = choose(policy, kind, env, prng, t)
             kwargs = dict(use_action_masking=masking, check_overflow=check_overflow)
@@ -137,6 +139,7 @@ def run_scenario(sc):
             obs, rew, term, trunc, info = env.step(a, **kwargs)
             assert trunc is False
             record(0, a, sm if kind == "press" else -1, flags, obs, rew, term)
+            agent_obs.append(agent.last_obs if kind == "press" else np.zeros(13, dtype=np.float32))
             if term and check_overflow:
                 break  # overflow-terminated: go to the next seeded reset
     out = {k: np.asarray(v) for k, v in rows.items()}
@@ -147,6 +150,9 @@ def run_scenario(sc):
     out["terminated"] = out["terminated"].astype(np.uint8)
     out["rng"] = out["rng"].astype(np.uint64)
     assert out["obs"].shape[1] == D and out["mask"].shape[1] == A
+    if kind == "press":
+        out["agent_obs"] = np.asarray(agent_obs, dtype=np.float32)
+        assert out["agent_obs"].shape == (len(out["op"]), 13)
     meta = dict(name=name, kind=kind, max_steps=kw["max_steps"], noise_sorting=kw["noise_sorting"],
                 balesize=kw["balesize"], ctor_seed=int(seeds[0]), policy=policy, masking=bool(masking),
                 check_overflow=bool(check_overflow), numpy=np.__version__,
@@ -160,7 +166,10 @@ def main():
         raise SystemExit("reference checkout not available: fixtures can only be generated in the build container")
     os.makedirs(OUT_DIR, exist_ok=True)
     total = 0
+    only = [a.split("=", 1)[1] for a in sys.argv if a.startswith("--only=")]
     for sc in scenarios():
+        if only and not any(sc[0].startswith(o) for o in only):
+            continue
         name, out = run_scenario(sc)
         path = os.path.join(OUT_DIR, name + ".npz")
         np.savez_compressed(path, **out)

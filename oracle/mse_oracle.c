@@ -533,6 +533,16 @@ static int update_environment(orc_env *e)
     return 0;
 }
 
+/* What Env_2_Pressing.step hands its sorting agent (env_2_press.py:95-104): get_sort_obs() taken AFTER this
+ * step's flow update and before the sensor setting.  A preview: the env is not changed (the flow update is a
+ * function of the state; the occupancy draw it discards comes from an unobserved stream). */
+void orc_env_sort_agent_obs(const orc_env *e, float *o)
+{
+    orc_env tmp = *e; /* shallow copy: sort_obs reads no bale list */
+    update_environment(&tmp);
+    sort_obs(&tmp, o);
+}
+
 /* env_super.py:484-509 set_multisensor_mode + update_accuracy */
 static void update_accuracy(orc_env *e, int mode)
 {

@@ -133,6 +133,7 @@ int orc_env_step(orc_env *e, int32_t action, int32_t sort_mode, uint32_t flags,
 
 void orc_env_action_mask(const orc_env *e, uint8_t *mask_out);
 void orc_env_obs(const orc_env *e, float *obs_out);
+void orc_env_sort_agent_obs(const orc_env *e, float *obs13_out); /* env_2_press.py:101: the sorting agent's view */
 int  orc_env_obs_dim(const orc_env *e);
 int  orc_env_num_actions(const orc_env *e);
 

@@ -108,6 +108,7 @@ def lib() -> C.CDLL:
         L.orc_env_step.restype = C.c_int
         L.orc_env_action_mask.argtypes = [C.c_void_p, P(C.c_uint8)]
         L.orc_env_obs.argtypes = [C.c_void_p, P(C.c_float)]
+        L.orc_env_sort_agent_obs.argtypes = [C.c_void_p, P(C.c_float)]
         L.orc_env_obs_dim.argtypes = [C.c_void_p]
         L.orc_env_obs_dim.restype = C.c_int
         L.orc_env_num_actions.argtypes = [C.c_void_p]
@@ -180,6 +181,12 @@ class OracleEnv:
     def obs(self):
         o = np.zeros(self.obs_dim, dtype=np.float32)
         self.L.orc_env_obs(self._h, o.ctypes.data_as(C.POINTER(C.c_float)))
+        return o
+
+    def sort_agent_obs(self):
+        """What Env_2_Pressing.step would hand its sorting agent on the next step (env_2_press.py:101)."""
+        o = np.zeros(13, dtype=np.float32)
+        self.L.orc_env_sort_agent_obs(self._h, o.ctypes.data_as(C.POINTER(C.c_float)))
         return o
 
     def snapshot(self):

@@ -93,8 +93,10 @@ class ScriptedSortAgent:
 
     def __init__(self):
         self.next_mode = 0
+        self.last_obs = None  # what the reference handed to predict(): get_sort_obs() after the step's flow update
 
     def predict(self, obs, deterministic=True):
+        self.last_obs = np.asarray(obs, dtype=np.float32).copy()
         return int(self.next_mode), None
 
 

@@ -79,6 +79,12 @@ def replay(path, make_driver, reward_tol=1e-6, skip_cols=(), skip_rng_words=None
             obs = drv.reset(int(z["arg"][t]))
             rew, term = 0.0, False
         else:
+            if "agent_obs" in z.files and hasattr(drv, "sort_agent_obs"):
+                # the observation the reference gave Env_2's sorting agent inside this step (env_2_press.py:101-104)
+                got = np.asarray(drv.sort_agent_obs(), dtype=np.float32)
+                exp = z["agent_obs"][t]
+                assert np.array_equal(exp.view(np.uint32), got.view(np.uint32)), \
+                    f"{tag} row {t}: sorting agent's observation differs: {exp} vs {got}"
             obs, rew, term = drv.step(int(z["arg"][t]), int(z["sort_mode"][t]), int(z["flags"][t]))
         compare_row(tag, z, t, obs, rew, term, drv.action_masks(), drv.snapshot(), reward_tol, skip_cols,
                     skip_rng_words)

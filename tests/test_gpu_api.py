@@ -153,3 +153,40 @@ def test_rule_based_policy_matches_reference_benchmark():
         cum = rew.sum(1)
         assert abs(cum.mean() - 44.18) < 0.01 and abs(cum.std() - 1.38) < 0.01
         assert bool(buf["done"][-1].all()) and int(buf["done"][:-1].sum()) == 0
+
+
+def test_env2_view_hands_its_sort_agent_the_reference_observation():
+    """Env_2_Pressing.set_agents(sort_agent=...): predict() must receive what the reference's Env_2.step passes
+    (get_sort_obs() after the step's flow update, env_2_press.py:101-104) - compared with the observations the
+    imported reference gave its agent when the fixture was generated."""
+    import numpy as np
+
+    import marl_sortingenv_amd as M
+    from tests import replay
+
+    class Agent:
+        def __init__(self):
+            self.next_mode, self.seen = 0, []
+
+        def predict(self, obs, deterministic=True):
+            self.seen.append(np.asarray(obs, dtype=np.float32).copy())
+            return self.next_mode, None
+
+    meta, z = replay.load(os.path.join(replay.GOLDEN_DIR, "press_n5_masked_s0_s3.npz"))
+    env = M.Env_2_Pressing(max_steps=meta["max_steps"], seed=meta["ctor_seed"], noise_sorting=meta["noise_sorting"],
+                           balesize=meta["balesize"])
+    agent = Agent()
+    env.set_agents(sort_agent=agent)
+    steps = 0
+    for t in range(len(z["op"])):
+        if z["op"][t] == 1:
+            env.reset(seed=int(z["arg"][t]))
+            continue
+        agent.next_mode = int(z["sort_mode"][t])
+        obs, rew, term, trunc, info = env.step(int(z["arg"][t]))
+        assert np.array_equal(agent.seen[-1].view(np.uint32), z["agent_obs"][t].view(np.uint32)), t
+        assert np.array_equal(np.asarray(obs, dtype=np.float32).view(np.uint32), z["obs"][t].view(np.uint32)), t
+        assert abs(rew - float(z["reward"][t])) <= 1e-6
+        steps += 1
+        if steps >= 120:
+            break

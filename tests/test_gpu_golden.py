@@ -54,6 +54,9 @@ class GpuDriver:
     def action_masks(self):
         return self.env.action_masks()[0].cpu().numpy()
 
+    def sort_agent_obs(self):
+        return self.env.sort_agent_obs()[0].cpu().numpy()
+
     def snapshot(self):
         ints, dbls, rng = self.env.get_state()
         d = np.concatenate([dbls[0].cpu().numpy(), self.acc_sorter])

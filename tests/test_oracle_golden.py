@@ -25,6 +25,9 @@ class OracleDriver:
     def snapshot(self):
         return self.env.snapshot()
 
+    def sort_agent_obs(self):
+        return self.env.sort_agent_obs()
+
 
 @pytest.mark.parametrize("path", replay.fixtures(), ids=lambda p: os.path.basename(p)[:-4])
 def test_oracle_matches_golden(path):

@@ -1,0 +1,70 @@
+"""On-device rollout collection with a learned policy (the caller side of the path).
+
+SB3's `collect_rollouts` (the loop inside `model.learn`, src/training.py:191) alternates policy forward and
+`env.step` on the host, one env at a time.  `PolicyRolloutCollector` does the same alternation for N envs with both
+halves on the device - `mse_policy_forward` then `mse_step` - and fills buffers shaped like SB3's
+`MaskableRolloutBuffer` ([K, N, ...]: observations, action masks, actions, log-probabilities, values, rewards,
+episode starts), so a learner can consume them without a host copy.  For `Env_2_Pressing` an optional sorting policy
+(13 -> 2, evaluated deterministically on `mse_sort_agent_obs`, env_2_press.py:101-104) plays the pre-trained sorting
+agent.  Two launches per step; the fully fused K-step kernel exists for the built-in policies (`rollout`).
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from .batched import BatchedSortingEnv
+from .policy import MlpPolicy
+
+
+class PolicyRolloutCollector:
+    def __init__(self, env: BatchedSortingEnv, policy: MlpPolicy, n_steps: int, sort_policy: Optional[MlpPolicy] = None,
+                 seed: int = 2024):
+        if policy.obs_dim != env.obs_dim or policy.n_actions != env.num_actions:
+            raise ValueError("policy dimensions do not match the env")
+        if sort_policy is not None and (env.kind != "press" or sort_policy.obs_dim != 13 or sort_policy.n_actions != 2):
+            raise ValueError("a sorting policy (13 -> 2) only applies to Env_2_Pressing")
+        if not env.auto_reset:
+            raise ValueError("collection needs auto_reset=True (episodes end inside a rollout)")
+        self.env, self.policy, self.sort_policy = env, policy, sort_policy
+        self.n_steps, self.seed, self.t = int(n_steps), int(seed), 0
+        n, K, dev = env.num_envs, self.n_steps, env.device
+        self.buffers = {
+            "observations": torch.empty((K, n, env.obs_dim), dtype=torch.float32, device=dev),
+            "action_masks": torch.empty((K, n, env.num_actions), dtype=torch.uint8, device=dev),
+            "actions": torch.empty((K, n), dtype=torch.int32, device=dev),
+            "log_probs": torch.empty((K, n), dtype=torch.float32, device=dev),
+            "values": torch.empty((K, n), dtype=torch.float32, device=dev),
+            "rewards": torch.empty((K, n), dtype=torch.float32, device=dev),
+            "episode_starts": torch.empty((K, n), dtype=torch.uint8, device=dev),
+        }
+        self._last_done = torch.ones((n,), dtype=torch.uint8, device=dev)  # the envs were just reset
+        self._out = None
+        self._sort_out = None
+
+    def collect(self, deterministic: bool = False) -> dict:
+        """K steps; returns the buffers plus `last_values` f32[N] (the bootstrap value of the state after the last
+        step) and `last_dones`, as SB3's compute_returns_and_advantage wants them."""
+        env, b = self.env, self.buffers
+        for k in range(self.n_steps):
+            obs, mask = env.obs, env.mask
+            b["observations"][k].copy_(obs)
+            b["action_masks"][k].copy_(mask)
+            b["episode_starts"][k].copy_(self._last_done)
+            self._out = self.policy.forward(obs, mask, seed=self.seed, t=self.t, deterministic=deterministic,
+                                            index_offset=env.index_offset, out=self._out)
+            sort_mode = None
+            if self.sort_policy is not None:
+                self._sort_out = self.sort_policy.forward(env.sort_agent_obs(), None, deterministic=True, out=self._sort_out)
+                sort_mode = self._sort_out["action"]
+            b["actions"][k].copy_(self._out["action"])
+            b["log_probs"][k].copy_(self._out["logp"])
+            b["values"][k].copy_(self._out["value"])
+            _, rew, done, _ = env.step(self._out["action"], sort_mode=sort_mode)
+            b["rewards"][k].copy_(rew)
+            self._last_done.copy_(done)
+            self.t += 1
+        last = self.policy.forward(env.obs, env.mask, seed=self.seed, t=self.t, deterministic=True,
+                                   index_offset=env.index_offset)
+        return dict(b, last_values=last["value"], last_dones=self._last_done.clone())

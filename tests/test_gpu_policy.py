@@ -149,3 +149,33 @@ def test_policy_abi_errors():
     assert L.mse_policy_create(C.byref(h), 29, 22, None, 0) == -1
     assert b"mse_policy_create" in L.mse_last_error()
     assert L.mse_policy_num_weights(29, 22) == 2 * (32 * 29 + 32 + 32 * 32 + 32) + 22 * 32 + 22 + 32 + 1
+
+
+@pytest.mark.parametrize("kind", ["mono", "press"])
+def test_collector_fills_rollout_buffers_consistently(kind):
+    """PolicyRolloutCollector: the buffers replay - stepping a twin env with the recorded actions (and, for Env_2,
+    the sorting decisions of the same sorting policy) reproduces the recorded observations, masks and rewards; the
+    recorded log-probabilities / values are those of the recorded observations."""
+    import torch
+
+    import marl_sortingenv_amd as M
+
+    n, K = 2000, 24
+    kw = dict(kind=kind, num_envs=n, device=0, base_seed=17, max_steps=10, noise_sorting=0.05, balesize=200)
+    env, twin = M.BatchedSortingEnv(**kw), M.BatchedSortingEnv(**kw)
+    pol = M.MlpPolicy(env.obs_dim, env.num_actions, _weights(env.obs_dim, env.num_actions, seed=21), device=0)
+    sort_pol = M.MlpPolicy(13, 2, _weights(13, 2, seed=22), device=0) if kind == "press" else None
+    col = M.PolicyRolloutCollector(env, pol, K, sort_policy=sort_pol, seed=5)
+    out = col.collect()
+    assert int(out["episode_starts"][0].sum()) == n and int(out["episode_starts"].sum()) == n * (1 + (K - 1) // 10)
+    for k in range(K):
+        assert torch.equal(out["observations"][k], twin.obs) and torch.equal(out["action_masks"][k], twin.mask)
+        again = pol.forward(twin.obs, twin.mask, seed=5, t=k)
+        assert torch.equal(again["action"], out["actions"][k])
+        assert torch.equal(again["logp"], out["log_probs"][k]) and torch.equal(again["value"], out["values"][k])
+        assert bool(torch.gather(twin.mask, 1, out["actions"][k].long().unsqueeze(1)).all())
+        sm = sort_pol.forward(twin.sort_agent_obs(), None, deterministic=True)["action"] if sort_pol else None
+        _, rew, done, _ = twin.step(out["actions"][k], sort_mode=sm)
+        assert torch.equal(rew, out["rewards"][k])
+    assert torch.equal(out["last_dones"], twin.done)
+    assert env.error_count() == 0

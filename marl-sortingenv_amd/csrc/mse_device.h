@@ -78,6 +78,8 @@ struct Params {
     int k_thr[4];           // hundredths of python round(quality_threshold, 2): purity of an empty container
     // offsets (in 4-byte words) into the table image; see build_tables
     int off_lvl, off_pdiff, off_timer0, off_timer1, off_tanh, off_eff, off_pat, off_acc, off_bonus, off_ptime, off_cst, off_jump, off_back, table_words;
+    uint32_t qi_down[4]; // bit q set: int((q / 100.0) * 100.0) == q - 1  (press_bale's stored quality)
+    int rem_thr_units;   // floor(bale_standard_size * bale_remainder_threshold)
     int ring_worst; // most sort_material draws one step can make with this config (k_rollout_ring flow control)
 };
 
@@ -986,15 +988,42 @@ __device__ __forceinline__ int purity_hundredths(int tru, int total)
     return (int)rint(((double)tru / (double)total) * 100.0);
 }
 
-// env_super.py:661-687 press_bale on the O(1) ledger summary {count, sum, last_size, last_q}
-__device__ __forceinline__ void press_bale(uint4 *cell, int balesize, double rem_thr, int n, int q100)
+// amount // S and amount % S for 0 <= amount < 2^24 without a division: fp32 estimate, exact fix-up
+__device__ __forceinline__ void divmod_small(int amount, int S, float inv_S, int &q, int &r)
+{
+    q = (int)((float)amount * inv_S);
+    r = amount - q * S;
+    if (r < 0) {
+        q -= 1;
+        r += S;
+    } else if (r >= S) {
+        q += 1;
+        r -= S;
+    }
+}
+
+// env_super.py:661-687 press_bale on the O(1) ledger summary {count, sum, last_size, last_q}.
+// The reference's three floating-point expressions here are functions of small integers and are evaluated as
+// such (a finishing press is a per-lane rarity but a per-wave certainty, so this path runs almost every step):
+//   int(q * 100) with q = round(x, 2) = q100 / 100.0   ->  q100 minus a bit of P.qi_down (the 101 cases, found by the
+//                                                          host with the literal expression: 0.29 -> 28, 0.57 -> 56, ...)
+//   floor(n / S)                                       ->  integer division (exact: the quotient of two int32 as a
+//                                                          double is within 2^-52 of the true value, never across an integer)
+//   rem > S * bale_remainder_threshold                 ->  rem > P.rem_thr_units = floor(S * thr), same test on integers
+__device__ __forceinline__ void press_bale(uint4 *cell, const Params &P, int n, int q100)
 {
     uint4 c = *cell;
-    double q = (double)q100 / 100.0;          // the stored quality round(x, 2)
-    uint32_t qi = (uint32_t)(int)(q * 100.0); // int(q*100) truncates (0.29 -> 28)
-    uint32_t S = (uint32_t)balesize;
-    uint32_t full = (uint32_t)floor((double)n / (double)S); // exact for int32 operands
-    uint32_t rem = (uint32_t)n - full * S;
+    const uint32_t w = (uint32_t)q100 >> 5;
+    const uint32_t word = w == 0 ? P.qi_down[0] : (w == 1 ? P.qi_down[1] : (w == 2 ? P.qi_down[2] : P.qi_down[3]));
+    const uint32_t qi = (uint32_t)q100 - ((word >> ((uint32_t)q100 & 31u)) & 1u);
+    const uint32_t S = (uint32_t)P.balesize;
+    int full_i, rem_i;
+    if (__builtin_expect(n < (1 << 24), 1)) divmod_small(n, P.balesize, P.inv_balesize, full_i, rem_i);
+    else {
+        full_i = (int)floor((double)n / (double)S);
+        rem_i = n - full_i * (int)S;
+    }
+    const uint32_t full = (uint32_t)full_i, rem = (uint32_t)rem_i;
     if (full > 0) {
         c.x += full;
         c.y += full * S;
@@ -1002,7 +1031,7 @@ __device__ __forceinline__ void press_bale(uint4 *cell, int balesize, double rem
         c.w = qi;
     }
     if (rem > 0) {
-        if ((double)rem > (double)S * rem_thr) {
+        if ((int)rem > P.rem_thr_units) {
             c.x += 1;
             c.y += rem;
             c.z = rem;
@@ -1037,7 +1066,7 @@ __device__ __forceinline__ void press_action_rules(Env &e, const Params &P, cons
         if (e.timer[p] > 0) {
             e.timer[p] -= 1;
             if (e.timer[p] == 0) {
-                if (P.track_bales) press_bale(bales.cell(e.pmat[p]), P.balesize, cst[CST_REM_THR], e.pn[p], e.q100[p]);
+                if (P.track_bales) press_bale(bales.cell(e.pmat[p]), P, e.pn[p], e.q100[p]);
                 e.pmat[p] = 0xFF;
                 e.pn[p] = 0;
                 e.q100[p] = 0;
@@ -1234,20 +1263,6 @@ __device__ __forceinline__ void clear_bales(const BaleRef &bales)
     for (int m = 0; m < 5; ++m) *bales.cell(m) = make_uint4(0, 0, 0, 0);
 }
 
-
-// amount // S and amount % S for 0 <= amount < 2^24 without a division: fp32 estimate, exact fix-up
-__device__ __forceinline__ void divmod_small(int amount, int S, float inv_S, int &q, int &r)
-{
-    q = (int)((float)amount * inv_S);
-    r = amount - q * S;
-    if (r < 0) {
-        q -= 1;
-        r += S;
-    } else if (r >= S) {
-        q += 1;
-        r -= S;
-    }
-}
 
 // What the reward / observation side needs of an env after its dynamics ran (before any auto-reset).
 // One env transition = env_dynamics (state-critical: flow, accuracy, sort_material, presses, flag

@@ -1440,6 +1440,14 @@ int mse_create_indexed(mse_env **out, const mse_config *cfg, int64_t n_envs, int
     P.press_time[0] = P.press_time0 = cfg->press_time[0];
     P.press_time[1] = P.press_time1 = cfg->press_time[1];
     P.inv_balesize = 1.0f / (float)cfg->bale_standard_size;
+    for (int w = 0; w < 4; ++w) P.qi_down[w] = 0;
+    for (int q = 0; q <= 100; ++q) { // env_super.py:664-666 with the literal expressions
+        const double qd = (double)q / 100.0;
+        const int qi = (int)(qd * 100.0);
+        if (qi != q) P.qi_down[q >> 5] |= 1u << (q & 31);
+        if (qi != q && qi != q - 1) return fail(MSE_ERR_UNSUPPORTED_CONFIG, "int(q*100) is not q or q-1");
+    }
+    P.rem_thr_units = (int)std::floor((double)cfg->bale_standard_size * cfg->bale_remainder_threshold);
     P.max_state_reward = cfg->max_state_reward;
     std::vector<uint32_t> image;
     std::string why;

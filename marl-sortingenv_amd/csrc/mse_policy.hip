@@ -95,11 +95,13 @@ __global__ __launch_bounds__(512) void k_policy_mlp(PolicyArgs P, const float *_
     for (long long tile = wave; tile < n_tiles; tile += n_waves) {
         const long long env = tile * kTile + j;
         const bool valid = env < P.n;
+        const long long env_c = valid ? env : 0; // clamp: loads of padding lanes stay in bounds, results unused
         float x[16];
 #pragma unroll
-        for (int s = 0; s < 16; ++s) {
+        for (int s = 0; s < 16; ++s) { // unconditional loads at clamped indices, then a select: no exec-mask regions
             const int k_in = 2 * s + h;
-            x[s] = (valid && k_in < D) ? obs[env * D + k_in] : 0.0f;
+            const float v = obs[env_c * D + (k_in < D ? k_in : 0)];
+            x[s] = k_in < D ? v : 0.0f;
         }
         // critic
         f32x16 vc;
@@ -143,15 +145,20 @@ __global__ __launch_bounds__(512) void k_policy_mlp(PolicyArgs P, const float *_
         for (int s = 0; s < 16; ++s) lg = __builtin_amdgcn_mfma_f32_32x32x2f32(a3[s * 64], acc2[s], lg, 0, 0, 0);
         // masked logits: this lane owns actions row_of(r, h) < A of env j.  Everything below is selects, no branches:
         // a per-register `if` turns into an exec-mask region each, and sixteen of them cost more than the MFMAs.
-        const long long env_c = valid ? env : 0; // clamp: loads of padding lanes stay in bounds, results unused
-        const bool use_mask = mask != nullptr;
         float m = -3.0e38f;
+        uint32_t allowed = 0xFFFFu; // bit r: the action in register r may be taken
+        if (mask != nullptr) {      // wave-uniform
+            allowed = 0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int a = row_of(r, h);
+                allowed |= (mask[env_c * A + (a < A ? a : 0)] != 0 ? 1u : 0u) << r;
+            }
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int a = row_of(r, h);
-            const bool own = a < A;
-            const uint8_t mb = use_mask ? mask[env_c * A + (own ? a : 0)] : (uint8_t)1;
-            lg[r] = own ? (mb != 0 ? lg[r] : -1.0e8f) : -3.0e38f; // sb3_contrib: HUGE_NEG = -1e8 for masked actions
+            const bool own = row_of(r, h) < A;
+            lg[r] = own ? (((allowed >> r) & 1u) ? lg[r] : -1.0e8f) : -3.0e38f; // sb3_contrib: HUGE_NEG = -1e8
             m = fmaxf(m, lg[r]);
         }
         if (logits_out != nullptr) { // wave-uniform

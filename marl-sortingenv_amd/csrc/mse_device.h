@@ -753,7 +753,7 @@ __device__ __forceinline__ void draw_units(RNG &rng, uint32_t &C, int &rem)
     while (rem > 0) {
         const uint32_t T = C >> 24;
         const uint32_t r_hi = rng.next_hi32();
-        uint32_t flags; // bit 7 of byte k set iff bin k is passed over (c_k <= v)
+        uint32_t flags = 0; // bit 7 of byte k set iff bin k is passed over (c_k <= v)
         bool literal = LITERAL;
         if (!LITERAL) {
             const uint64_t prod = mul64_vv(r_hi, T);
@@ -771,7 +771,6 @@ __device__ __forceinline__ void draw_units(RNG &rng, uint32_t &C, int &rem)
     }
 }
 
-// station I: true = rint(target * acc), false = target - true, leftover[I] = false (env_super.py:535-546)
 // The draw loop when the outputs come from the LDS ring.
 //
 // The dynamics wave is one wave on its SIMD that matters (the observer and RNG waves have slack), and a single
@@ -860,6 +859,7 @@ __device__ __forceinline__ void draw_units_ring(RngRing &rng, uint32_t &C, int &
 #endif
 }
 
+// station I: true = rint(target * acc), false = target - true, leftover[I] = false (env_super.py:535-546)
 template <int I>
 __device__ __forceinline__ void station_split(Env &e, uint32_t &C, const double acc_sorter[4], int &rem)
 {
@@ -1058,8 +1058,7 @@ struct BaleRef {
 };
 
 // env_super.py:626-640 press_action_rules = check_press_status (:642-659) then use_press (:722-769)
-__device__ __forceinline__ void press_action_rules(Env &e, const Params &P, const double *cst, int press_action,
-                                                   const BaleRef &bales)
+__device__ __forceinline__ void press_action_rules(Env &e, const Params &P, int press_action, const BaleRef &bales)
 {
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
@@ -1164,7 +1163,7 @@ __device__ __forceinline__ Tables tables_at(const uint32_t *base, const Params &
 __device__ __forceinline__ float clip_f(float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
 // env_super.py:306-325 get_sort_obs -> o[0..12]
-__device__ __forceinline__ void sort_obs(const Env &e, const Params &P, const Tables &tb, const int k[4], float *o)
+__device__ __forceinline__ void sort_obs(const Env &e, const Tables &tb, const int k[4], float *o)
 {
     const uint32_t *rec = tb.pat + e.st_belt * kPatStride;
     o[0] = __uint_as_float(rec[1]); // belt_occupancy = the input occupancy of the batch that is now on the belt
@@ -1217,11 +1216,11 @@ template <int KIND>
 __device__ __forceinline__ void env_obs(const Env &e, const Params &P, const Tables &tb, const int k[4], float *o)
 {
     if (KIND == 1) {
-        sort_obs(e, P, tb, k, o);
+        sort_obs(e, tb, k, o);
     } else if (KIND == 2) {
         press_obs(e, P, tb, o);
     } else {
-        sort_obs(e, P, tb, k, o);
+        sort_obs(e, tb, k, o);
         press_obs(e, P, tb, o + 13);
     }
 }
@@ -1346,7 +1345,7 @@ __device__ __forceinline__ void env_dynamics(Env &e, RNG &rng, const Params &P, 
         if (unmasked && !press_action_valid(e, P, press_action)) press_action = 0;
     }
 #ifndef MSE_ABL_NOPRESS
-    if (run_press_rules) press_action_rules(e, P, tb.cst, press_action, bales);
+    if (run_press_rules) press_action_rules(e, P, press_action, bales);
 #endif
     MSE_TL(e.tl, 3);
 

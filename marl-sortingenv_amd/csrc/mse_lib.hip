@@ -884,7 +884,7 @@ __global__ __launch_bounds__(kBlock) void k_sort_agent_obs(Params P, const uint4
     int k[4];
     container_purity_k(e, k);
     float o[13];
-    sort_obs(e, P, tb, k, o);
+    sort_obs(e, tb, k, o);
 #pragma unroll
     for (int j = 0; j < 13; ++j) obs_out[i * 13 + j] = o[j];
 }

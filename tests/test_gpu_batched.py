@@ -192,6 +192,27 @@ def test_pipelined_rollout_equals_single_role_rollout(kind, noise, pipeline):
             assert torch.equal(x, y), chunk
 
 
+@pytest.mark.parametrize("kind", KINDS)
+def test_ring_rollout_launch_boundaries_around_resets(kind):
+    """Launches that end one or two steps after an auto-reset (the sorting stage is empty there, nothing is drawn,
+    so the RNG lanes stand up to 2 x worst outputs ahead when they hand the stream back: the two-stage step back),
+    launches of one, two and three steps, and launches that begin right after a reset - all against the one-lane-per-env
+    kernel, buffers and final state (incl. the PCG64 stream position)."""
+    import torch
+
+    n = 777
+    kw = dict(base_seed=99, max_steps=10, noise_sorting=0.0, balesize=200, auto_reset=True)
+    a = _mk(kind, n, rollout_pipeline=3, **kw)
+    b = _mk(kind, n, rollout_pipeline=2, **kw)
+    for chunk in (12, 9, 1, 1, 2, 3, 13, 16, 11, 1):  # ends at steps 12, 21, 22, 23, 25, 28, 41, 57, 68, 69
+        ra, rb = a.rollout(chunk, policy_seed=4), b.rollout(chunk, policy_seed=4)
+        for key in ra:
+            assert torch.equal(ra[key], rb[key]), (key, chunk)
+        for x, y in zip(a.get_state(), b.get_state()):
+            assert torch.equal(x, y), chunk
+    assert a.error_count() == 0
+
+
 def test_ring_kernel_refuses_configs_with_too_many_draws():
     import marl_sortingenv_amd as M
     from marl_sortingenv_amd._lib import MseError

@@ -53,7 +53,11 @@ class SortingEnvConfig:
         import yaml
 
         with open(path, "r") as f:
-            y = yaml.safe_load(f)
+            return cls.from_dict(yaml.safe_load(f))
+
+    @classmethod
+    def from_dict(cls, y: dict) -> "SortingEnvConfig":
+        """From a mapping with config.yml's schema (simulation / sorting_station / pressing_station / rewards)."""
         sim, srt, prs, rew = y["simulation"], y["sorting_station"], y["pressing_station"], y["rewards"]
         q = prs["bale_quality_thresholds"]
         return cls(
@@ -74,6 +78,46 @@ class SortingEnvConfig:
             max_state_reward=rew["pressing"]["max_state_reward"],
             overflow_termination_penalty=rew["overflow_termination_penalty"],
         )
+
+    def to_dict(self) -> dict:
+        """The same values in config.yml's schema (only the keys the step path reads)."""
+        q = self.bale_quality_thresholds
+        return {
+            "simulation": {"input_occupancy_min": self.input_occupancy_min, "input_occupancy_max": self.input_occupancy_max,
+                           "input_batch_size": self.input_batch_size, "steps_per_pattern": self.steps_per_pattern},
+            "sorting_station": {"baseline_accuracy": list(self.baseline_accuracy), "boost": self.boost, "noise": self.noise,
+                                "stage_capacity": self.stage_capacity},
+            "pressing_station": {"press_times": {1: self.press_times[0], 2: self.press_times[1]},
+                                 "container_capacity": self.container_capacity,
+                                 "bale_standard_size": self.bale_standard_size,
+                                 "bale_remainder_threshold": self.bale_remainder_threshold,
+                                 "bale_quality_thresholds": {"A": q[0], "B": q[1], "C": q[2], "D": q[3]}},
+            "rewards": {"sorting": {"purity_threshold_theta": self.purity_threshold_theta,
+                                    "tanh_temperature": self.tanh_temperature},
+                        "pressing": {"overflow_penalty_catastrophic": self.overflow_penalty_catastrophic,
+                                     "overflow_penalty_severe": self.overflow_penalty_severe,
+                                     "overflow_penalty_mild": self.overflow_penalty_mild,
+                                     "bale_efficiency_factor": self.bale_efficiency_factor,
+                                     "max_state_reward": self.max_state_reward},
+                        "overflow_termination_penalty": self.overflow_termination_penalty},
+        }
+
+    def with_overrides(self, overrides: dict) -> "SortingEnvConfig":
+        """A copy with a nested dict in config.yml's schema merged over this config."""
+        def merge(a, b):
+            for k, v in b.items():
+                if isinstance(v, dict) and isinstance(a.get(k), dict):
+                    merge(a[k], v)
+                else:
+                    a[k] = v
+            return a
+
+        def intkeys(d):  # JSON turns press_times' integer keys into strings
+            return {(int(k) if isinstance(k, str) and k.isdigit() else k): (intkeys(v) if isinstance(v, dict) else v)
+                    for k, v in d.items()}
+
+        return dataclasses.replace(type(self).from_dict(merge(self.to_dict(), intkeys(overrides))),
+                                   pattern_ratios=self.pattern_ratios, extra=dict(self.extra))
 
     def to_struct(self, kind: str, max_steps: int = 50, noise_sorting=None, balesize=None,
                   auto_reset: bool = True, track_bales: bool = True, literal_choice: bool = False,

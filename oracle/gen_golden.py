@@ -53,7 +53,56 @@ def scenarios():
                   [1, 2], "noop", True, True, 90))
         S.append((f"{kind}_n5_greedy_s5_bale150_T50", kind, dict(max_steps=50, noise_sorting=0.05, balesize=150),
                   [5, 6, 99991], "greedy_press", True, False, 60))
+    # a config.yml other than the reference's own (every value the step path reads that config.yml can change),
+    # written to a scratch directory the reference env is constructed in
+    for name, kind, kw, seeds, policy, masking, seg in (
+            ("mono_cfgA_n5_masked_s2_s11", "mono", dict(max_steps=60, noise_sorting=0.05, balesize=150), [2, 11], "masked_uniform", True, 75),
+            ("press_cfgA_n0_unmasked_s4_s8", "press", dict(max_steps=60, noise_sorting=0.0, balesize=150), [4, 8], "ignore_mask_uniform", False, 75),
+            ("sort_cfgA_n5_masked_s6_s9", "sort", dict(max_steps=60, noise_sorting=0.05, balesize=150), [6, 9], "masked_uniform", True, 75),
+            ("mono_cfgA_n0_greedy_s7", "mono", dict(max_steps=80, noise_sorting=0.0, balesize=150), [7, 13], "greedy_press", True, 85)):
+        S.append((name, kind, kw, seeds, policy, masking, False, seg, CONFIG_A))
     return S
+
+
+CONFIG_A = {
+    "simulation": {"steps_per_pattern": 7},
+    "sorting_station": {"baseline_accuracy": [0.7, 0.8, 0.65, 0.9], "boost": 0.2},
+    "pressing_station": {"press_times": {1: 8, 2: 20}, "container_capacity": 500, "bale_remainder_threshold": 0.4,
+                         "bale_quality_thresholds": {"A": 0.85, "B": 0.9, "C": 0.8, "D": 0.95}},
+    "rewards": {"sorting": {"purity_threshold_theta": 0.75, "tanh_temperature": 0.7},
+                "pressing": {"overflow_penalty_catastrophic": -0.9, "overflow_penalty_severe": -0.4,
+                             "overflow_penalty_mild": -0.1, "bale_efficiency_factor": 0.8, "max_state_reward": 0.4},
+                "overflow_termination_penalty": -7.5},
+}
+
+
+def _construct(cls, seed, kw, overrides):
+    """Env(...) with the reference's config.yml, or with a merged copy of it in a scratch CWD."""
+    if not overrides:
+        return cls(seed=seed, **kw)
+    import tempfile
+
+    import yaml
+
+    def merge(a, b):
+        for k, v in b.items():
+            if isinstance(v, dict) and isinstance(a.get(k), dict):
+                merge(a[k], v)
+            else:
+                a[k] = v
+        return a
+
+    with open(os.path.join(ref_harness.REFERENCE_ROOT, "config.yml")) as f:
+        cfg = merge(yaml.safe_load(f), overrides)
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as d:
+        with open(os.path.join(d, "config.yml"), "w") as f:
+            yaml.safe_dump(cfg, f)
+        os.chdir(d)
+        try:
+            return cls(seed=seed, **kw)  # reads ./config.yml (env_super.py:25-29)
+        finally:
+            os.chdir(cwd)
 
 
 def choose(policy, kind, env, prng, t):
@@ -98,9 +147,10 @@ def choose(policy, kind, env, prng, t):
 
 
 def run_scenario(sc):
-    name, kind, kw, seeds, policy, masking, check_overflow, seg = sc
+    name, kind, kw, seeds, policy, masking, check_overflow, seg = sc[:8]
+    overrides = sc[8] if len(sc) > 8 else None
     classes = ref_harness.load()
-    env = classes[kind](seed=seeds[0], **kw)
+    env = _construct(classes[kind], seeds[0], kw, overrides)
     agent = None
     if kind == "press":
         agent = ref_harness.ScriptedSortAgent()
@@ -155,7 +205,7 @@ def run_scenario(sc):
         assert out["agent_obs"].shape == (len(out["op"]), 13)
     meta = dict(name=name, kind=kind, max_steps=kw["max_steps"], noise_sorting=kw["noise_sorting"],
                 balesize=kw["balesize"], ctor_seed=int(seeds[0]), policy=policy, masking=bool(masking),
-                check_overflow=bool(check_overflow), numpy=np.__version__,
+                check_overflow=bool(check_overflow), numpy=np.__version__, config_overrides=overrides or {},
                 generator="oracle/gen_golden.py from the imported reference")
     out["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
     return name, out

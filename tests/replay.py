@@ -30,6 +30,40 @@ def fixtures(kind=None):
     return paths
 
 
+def sorting_config(meta):
+    """The package's config for a fixture: config.yml's values with the fixture's overrides (if any) merged in."""
+    from marl_sortingenv_amd.config import SortingEnvConfig
+
+    cfg = SortingEnvConfig()
+    ov = meta.get("config_overrides") or {}
+    return cfg.with_overrides(ov) if ov else cfg
+
+
+def oracle_config(meta):
+    """The oracle's config struct for a fixture (same values, the oracle's own field names)."""
+    from oracle.oracle import default_config
+
+    c = default_config(meta["kind"], meta["max_steps"], meta["noise_sorting"], meta["balesize"])
+    ov = meta.get("config_overrides") or {}
+    if ov:
+        s = sorting_config(meta)
+        c.input_batch_size, c.steps_per_pattern = s.input_batch_size, s.steps_per_pattern
+        c.input_occupancy_min, c.input_occupancy_max = s.input_occupancy_min, s.input_occupancy_max
+        for m in range(4):
+            c.baseline_accuracy[m] = s.baseline_accuracy[m]
+            c.quality_threshold[m] = s.bale_quality_thresholds[m]
+        c.boost, c.stage_capacity = s.boost, s.stage_capacity
+        c.press_time[0], c.press_time[1] = s.press_times
+        c.container_capacity = s.container_capacity
+        c.bale_remainder_threshold = s.bale_remainder_threshold
+        c.purity_threshold_theta, c.tanh_temperature = s.purity_threshold_theta, s.tanh_temperature
+        c.overflow_penalty_catastrophic = s.overflow_penalty_catastrophic
+        c.overflow_penalty_severe, c.overflow_penalty_mild = s.overflow_penalty_severe, s.overflow_penalty_mild
+        c.bale_efficiency_factor, c.max_state_reward = s.bale_efficiency_factor, s.max_state_reward
+        c.overflow_termination_penalty = s.overflow_termination_penalty
+    return c
+
+
 def load(path):
     z = np.load(path, allow_pickle=False)
     meta = json.loads(bytes(z["meta"]).decode())

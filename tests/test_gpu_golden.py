@@ -28,7 +28,7 @@ class GpuDriver:
         self.env = M.BatchedSortingEnv(kind=meta["kind"], num_envs=1, device=0, base_seed=meta["ctor_seed"],
                                        max_steps=meta["max_steps"], noise_sorting=meta["noise_sorting"],
                                        balesize=meta["balesize"], auto_reset=False, literal_choice=literal_choice,
-                                       library=library)
+                                       library=library, config=replay.sorting_config(meta))
         self.prev_acc = None
         self.acc_sorter = None
 

@@ -10,7 +10,8 @@ from tests import replay
 class OracleDriver:
     def __init__(self, meta):
         self.env = OracleEnv(kind=meta["kind"], max_steps=meta["max_steps"], seed=meta["ctor_seed"],
-                             noise_sorting=meta["noise_sorting"], balesize=meta["balesize"])
+                             noise_sorting=meta["noise_sorting"], balesize=meta["balesize"],
+                             cfg=replay.oracle_config(meta))
 
     def reset(self, seed):
         return self.env.reset(seed)

@@ -132,20 +132,21 @@ def main():
                 act = env.sample_actions(policy_seed=2024)
                 env.step(act)
             return
-        # HIP events on the launch stream bracket the run of full-size launches as a whole: the launches are
-        # queued back to back (the host is far ahead of a 70 us kernel), so elapsed / launches is the kernel's
-        # duration plus the ~1.5 us dependent-kernel boundary, not an event round trip per launch
-        n_full = n_steps // chunk
-        if events is not None and n_full > 0:
+        # HIP events on the launch stream bracket the run of launches as a whole: they are queued back to back (the
+        # host is far ahead of a 70 us kernel), so elapsed / launches is the kernel's duration plus the ~1.5 us
+        # dependent-kernel boundary, not an event round trip per launch.  A last, shorter launch takes the steps
+        # that do not fill a chunk (e.g. --steps 5): the roofline divides by the steps actually taken.
+        n_full, tail = n_steps // chunk, n_steps % chunk
+        if events is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(stream)
         for _ in range(n_full):
             env.rollout(chunk, policy_seed=2024, buffers=buf)
-        if events is not None and n_full > 0:
+        if tail > 0:
+            env.rollout(tail, policy_seed=2024, buffers=buf)
+        if events is not None:
             e1.record(stream)
-            events.append((n_full, e0, e1))
-        if n_steps - n_full * chunk > 0:
-            env.rollout(n_steps - n_full * chunk, policy_seed=2024, buffers=buf)
+            events.append((n_full + (1 if tail else 0), n_steps, e0, e1))
 
     def barrier():
         if world > 1:
@@ -168,12 +169,17 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
-    # dominant kernel: k_rollout. HIP events on the launch stream around each launch of the timed region
-    full = [(cnt, e0.elapsed_time(e1)) for (cnt, e0, e1) in events]
-    per_launch_ms = sum(ms for _, ms in full) / max(1, sum(cnt for cnt, _ in full)) if full else float("nan")
+    # dominant kernel: the rollout kernel.  HIP events on the launch stream around the launches of the timed region
     bytes_per_step = env.algorithmic_bytes_per_step
-    algo_bytes_per_launch = bytes_per_step * n * chunk
-    achieved = algo_bytes_per_launch / (per_launch_ms * 1e-3) / 1e9 if full else float("nan")
+    if events:
+        launches = sum(c for c, _, _, _ in events)
+        steps_timed = sum(k for _, k, _, _ in events)
+        total_ms = sum(a.elapsed_time(b) for _, _, a, b in events)
+        per_launch_ms = total_ms / max(1, launches)
+        achieved = bytes_per_step * n * steps_timed / (total_ms * 1e-3) / 1e9
+        steps_per_launch_avg = steps_timed / max(1, launches)
+    else:  # --mode step: two kernels per step, no single dominant launch to quote
+        per_launch_ms, achieved, steps_per_launch_avg = None, None, 1
     assert env.error_count() == 0
 
     if rank == 0:
@@ -199,12 +205,13 @@ def main():
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBPS, "traffic": measured_traffic(args, n, chunk),
+                "frac": None if achieved is None else achieved / HBM_PEAK_GBPS,
+                "traffic": measured_traffic(args, n, chunk) if args.steps % chunk == 0 else None,
                 "kernel": ("k_sample + k_step" if args.mode == "step" else
                            {1: "k_rollout_po", 2: "k_rollout", 3: "k_rollout_ring"}.get(
                                args.pipeline, "k_rollout_ring" if n <= 131072 else "k_rollout")),
                 "launch_ms": per_launch_ms,
-                "algorithmic_bytes_per_env_step": bytes_per_step, "env_steps_per_launch": n * chunk,
+                "algorithmic_bytes_per_env_step": bytes_per_step, "env_steps_per_launch": n * steps_per_launch_avg,
             },
         }
         if world == 1 and not args.no_cpu_baseline:

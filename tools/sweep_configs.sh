@@ -6,5 +6,6 @@ for args in "--kind mono --envs 65536" "--kind sort --envs 65536" "--kind press 
   python bench.py --no-cpu-baseline $args 2>/dev/null | tail -1 | python -c "
 import json,sys
 d=json.loads(sys.stdin.read()); r=d['roofline']
-print('%-42s | G steps/s %6.2f | ms/step %.4f | launch_ms %.4f | frac %.3f | %s' % ('$args', d['value']/1e9, d['ms_per_step'], r['launch_ms'], r['frac'], r['kernel']))"
+f=lambda v, fmt: '  n/a ' if v is None else fmt % v
+print('%-42s | G steps/s %6.2f | ms/step %.4f | launch_ms %s | frac %s | %s' % ('$args', d['value']/1e9, d['ms_per_step'], f(r['launch_ms'], '%.4f'), f(r['frac'], '%.3f'), r['kernel']))"
 done

@@ -213,6 +213,29 @@ def test_ring_rollout_launch_boundaries_around_resets(kind):
     assert a.error_count() == 0
 
 
+def test_long_run_near_ties_in_the_shipped_window():
+    """65 536 envs x 20 000 steps = 1.6e10 draws: with the shipped window (2^-23 of the draws) some 2 000 of them sit
+    near a cdf boundary, so the three-role kernel's whole-step literal redo and the one-lane kernel's per-draw
+    fallback both run for real - against the one-lane kernel with EVERY draw decided by the literal fp64 cdf.
+    Rewards, dones, actions of every step and the final state (incl. PCG64 positions) must be identical."""
+    import torch
+
+    n, K, launches = 65536, 100, 200
+    kw = dict(base_seed=2025, max_steps=200, noise_sorting=0.0, balesize=200, auto_reset=True)
+    ring = _mk("mono", n, rollout_pipeline=3, **kw)
+    one = _mk("mono", n, rollout_pipeline=2, **kw)
+    lit = _mk("mono", n, rollout_pipeline=2, literal_choice=True, **kw)
+    bufs = [e.alloc_rollout(K, obs=False, mask=False) for e in (ring, one, lit)]
+    for _ in range(launches):
+        for e, b in zip((ring, one, lit), bufs):
+            e.rollout(K, policy_seed=77, buffers=b)
+        for key in ("actions", "reward", "done"):
+            assert torch.equal(bufs[0][key], bufs[2][key]) and torch.equal(bufs[1][key], bufs[2][key]), key
+    for x, y, z in zip(ring.get_state(), one.get_state(), lit.get_state()):
+        assert torch.equal(x, z) and torch.equal(y, z)
+    assert ring.error_count() == 0
+
+
 def test_ring_kernel_refuses_configs_with_too_many_draws():
     import marl_sortingenv_amd as M
     from marl_sortingenv_amd._lib import MseError

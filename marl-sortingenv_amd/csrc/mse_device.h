@@ -859,6 +859,91 @@ __device__ __forceinline__ void draw_units_ring(RngRing &rng, uint32_t &C, int &
 #endif
 }
 
+// The same hand-placed loop for a lane that advances its own generator (one-lane-per-env kernels: k_step,
+// k_rollout).  Per draw: the 128-bit LCG step on 32-bit limbs (6 v_mad_u64_u32 + 4 v_mul_lo_u32, the {carry, 0}
+// addends through one scratch pair), the upper half of the XSL-RR output, and the decision of draw_units_ring;
+// ~40 instructions against ~50 from the structured C++ loop.  Near ties are only recorded (f_min / f_max);
+// sort_material redoes the step literally when one shows.  Products and carries live in v[112:123].
+__device__ __forceinline__ void draw_units_local(Pcg &g, uint32_t &C, int &rem, uint32_t &f_min, uint32_t &f_max)
+{
+#ifdef MSE_ABL_NODRAW
+    rem = 0;
+#endif
+    uint32_t T = C >> 24;
+    const uint32_t n_draws = (uint32_t)rem;
+    const uint32_t T_end = T - n_draws;
+    uint32_t Cb = C - 0x00808080u;
+    uint32_t s0 = (uint32_t)g.s_lo, s1 = (uint32_t)(g.s_lo >> 32), s2 = (uint32_t)g.s_hi, s3 = (uint32_t)(g.s_hi >> 32);
+    const uint32_t i0 = (uint32_t)g.i_lo, i1 = (uint32_t)(g.i_lo >> 32), i2 = (uint32_t)g.i_hi, i3 = (uint32_t)(g.i_hi >> 32);
+    const uint32_t m0 = 0x9FCCF645u, m1 = 0x4385DF64u, m2 = 0x1FC65DA4u, m3 = 0x2360ED05u;
+    const uint32_t kSel = 0x0C000000u, kK = 0xFEFEFEFFu;
+    uint32_t t0, t1, t2, t3, x, y;
+    uint64_t sv, cm, dm;
+    asm volatile(
+        "s_mov_b64 %[sv], exec\n\t"
+        "v_cmp_ne_u32 vcc, 0, %[n]\n\t"
+        "s_and_b64 exec, exec, vcc\n\t"
+        "s_cbranch_execz 3f\n\t"
+        "v_mov_b32 v121, 0\n"
+        "1:\n\t"
+        /* state * M + inc  (mod 2^128) */
+        "v_mad_u64_u32 v[112:113], %[dm], %[s0], %[m0], 0\n\t"
+        "v_mul_lo_u32 %[t3], %[s3], %[m0]\n\t"
+        "v_mul_lo_u32 %[t0], %[s0], %[m3]\n\t"
+        "v_mov_b32 v120, v113\n\t"
+        "v_mad_u64_u32 v[114:115], %[dm], %[s0], %[m1], v[120:121]\n\t"
+        "v_mul_lo_u32 %[t1], %[s1], %[m2]\n\t"
+        "v_mul_lo_u32 %[t2], %[s2], %[m1]\n\t"
+        "v_mov_b32 v120, v114\n\t"
+        "v_mad_u64_u32 v[116:117], %[dm], %[s1], %[m0], v[120:121]\n\t"
+        "v_mov_b32 v120, v115\n\t"
+        "v_mad_u64_u32 v[118:119], %[dm], %[s0], %[m2], v[120:121]\n\t"
+        "v_add3_u32 %[t0], %[t0], %[t1], %[t2]\n\t"
+        "v_mad_u64_u32 v[118:119], %[dm], %[s1], %[m1], v[118:119]\n\t"
+        "v_mov_b32 v120, v117\n\t"
+        "v_mad_u64_u32 v[118:119], %[dm], %[s2], %[m0], v[118:119]\n\t"
+        "v_add_u32 %[t0], %[t0], %[t3]\n\t"
+        "v_lshl_add_u64 v[118:119], v[118:119], 0, v[120:121]\n\t"
+        "v_add_co_u32 %[s0], vcc, v112, %[i0]\n\t"
+        "v_addc_co_u32 %[s1], vcc, v116, %[i1], vcc\n\t"
+        "v_add_u32 %[t0], %[t0], v119\n\t"
+        "v_addc_co_u32 %[s2], vcc, v118, %[i2], vcc\n\t"
+        "v_addc_co_u32 %[s3], vcc, %[t0], %[i3], vcc\n\t"
+        /* upper 32 bits of rotr64(hi ^ lo, hi >> 58) */
+        "v_xor_b32 %[x], %[s0], %[s2]\n\t"
+        "v_xor_b32 %[y], %[s1], %[s3]\n\t"
+        "v_lshrrev_b32 %[t1], 26, %[s3]\n\t"
+        "v_cmp_gt_i32 vcc, 0, %[s3]\n\t"
+        "v_cndmask_b32 %[t2], %[x], %[y], vcc\n\t"
+        "v_cndmask_b32 %[t3], %[y], %[x], vcc\n\t"
+        "v_alignbit_b32 %[t2], %[t2], %[t3], %[t1]\n\t"
+        /* the draw: v = floor(u T), flags by byte compare, one unit leaves the chosen bin */
+        "v_mad_u64_u32 v[122:123], %[dm], %[t2], %[t], 0\n\t"
+        "v_add_u32 %[t], -1, %[t]\n\t"
+        "v_perm_b32 %[x], 0, v123, %[sel]\n\t"
+        "v_min_u32 %[mn], %[mn], v122\n\t"
+        "v_sub_u32 %[x], %[x], %[cb]\n\t"
+        "v_max_u32 %[mx], %[mx], v122\n\t"
+        "v_lshrrev_b32 %[x], 7, %[x]\n\t"
+        "v_cmp_ne_u32_e64 %[cm], %[t], %[tend]\n\t"
+        "v_and_b32 %[x], 0x10101, %[x]\n\t"
+        "v_add3_u32 %[cb], %[cb], %[x], %[k]\n\t"
+        "s_and_b64 exec, exec, %[cm]\n\t"
+        "s_cbranch_execnz 1b\n"
+        "3:\n\t"
+        "s_mov_b64 exec, %[sv]"
+        : [s0] "+v"(s0), [s1] "+v"(s1), [s2] "+v"(s2), [s3] "+v"(s3), [cb] "+v"(Cb), [t] "+v"(T), [mn] "+v"(f_min),
+          [mx] "+v"(f_max), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [x] "=&v"(x), [y] "=&v"(y),
+          [sv] "=&s"(sv), [cm] "=&s"(cm), [dm] "=&s"(dm)
+        : [i0] "v"(i0), [i1] "v"(i1), [i2] "v"(i2), [i3] "v"(i3), [m0] "s"(m0), [m1] "s"(m1), [m2] "s"(m2), [m3] "s"(m3),
+          [sel] "s"(kSel), [k] "s"(kK), [tend] "v"(T_end), [n] "v"(n_draws)
+        : "vcc", "memory", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123");
+    g.s_lo = (uint64_t)s0 | ((uint64_t)s1 << 32);
+    g.s_hi = (uint64_t)s2 | ((uint64_t)s3 << 32);
+    C = Cb + 0x00808080u;
+    rem = 0;
+}
+
 // station I: true = rint(target * acc), false = target - true, leftover[I] = false (env_super.py:535-546)
 template <int I>
 __device__ __forceinline__ void station_split(Env &e, uint32_t &C, const double acc_sorter[4], int &rem)
@@ -943,6 +1028,52 @@ __device__ __forceinline__ void sort_material(Env &e, RngRing &rng, uint32_t sor
         sort_material<true>(e, exact, sorting_word, acc_sorter);
         rng.p10 = p10_0 + (exact.count << 10);
     }
+}
+
+template <int I>
+__device__ __forceinline__ void station_pair_local(Env &e, Pcg &g, uint32_t &C, const double acc_sorter[4],
+                                                   uint32_t &f_min, uint32_t &f_max)
+{
+    int rem;
+    station_split<I>(e, C, acc_sorter, rem);
+    const bool early = rem == 0;
+    if (early) station_split<I + 1>(e, C, acc_sorter, rem);
+    draw_units_local(g, C, rem, f_min, f_max);
+    if (!early) {
+        station_split<I + 1>(e, C, acc_sorter, rem);
+        draw_units_local(g, C, rem, f_min, f_max);
+    }
+}
+
+// sort_material for a lane with its own generator and the integer decision (overload chosen for RngLocal,
+// LITERAL = false): hand-placed loops, then - if any draw of the step sat in the near-tie window - the step is
+// taken again from the saved generator and counters with every decision made by the literal fp64 cdf.
+__device__ __forceinline__ void sort_material_local_fast(Env &e, Pcg &g, uint32_t sorting_word, const double acc_sorter[4])
+{
+    const Pcg g0 = g;
+    const int ct0 = e.ct[0], ct1 = e.ct[1], ct2 = e.ct[2], ct3 = e.ct[3];
+    const int cf0 = e.cf[0], cf1 = e.cf[1], cf2 = e.cf[2], cf3 = e.cf[3];
+    const int ce0 = e.ce;
+    uint32_t f_min = 0xFFFFFFFFu, f_max = 0u;
+    uint32_t C = sorting_word * 0x01010101u;
+    station_pair_local<0>(e, g, C, acc_sorter, f_min, f_max);
+    station_pair_local<2>(e, g, C, acc_sorter, f_min, f_max);
+    e.ce += (int)(C >> 24);
+    if (__builtin_expect(f_min < MSE_TIE_WINDOW - 0x200u || f_max >= 0xFFFFFE00u, 0)) {
+        e.ct[0] = ct0; e.ct[1] = ct1; e.ct[2] = ct2; e.ct[3] = ct3;
+        e.cf[0] = cf0; e.cf[1] = cf1; e.cf[2] = cf2; e.cf[3] = cf3;
+        e.ce = ce0;
+        g = g0;
+        RngLocal exact{g};
+        sort_material<true>(e, exact, sorting_word, acc_sorter);
+    }
+}
+
+template <bool LITERAL>
+__device__ __forceinline__ void sort_material(Env &e, RngLocal &rng, uint32_t sorting_word, const double acc_sorter[4])
+{
+    if (LITERAL) sort_material<true, RngLocal>(e, rng, sorting_word, acc_sorter);
+    else sort_material_local_fast(e, rng.g, sorting_word, acc_sorter);
 }
 
 // buffered uint32 of PCG64 (pcg64.h pcg64_next32)

@@ -209,7 +209,7 @@ def main():
                 "traffic": measured_traffic(args, n, chunk) if args.steps % chunk == 0 else None,
                 "kernel": ("k_sample + k_step" if args.mode == "step" else
                            {1: "k_rollout_po", 2: "k_rollout", 3: "k_rollout_ring"}.get(
-                               args.pipeline, "k_rollout_ring" if n <= 131072 else "k_rollout")),
+                               args.pipeline, "k_rollout_ring" if n <= 65536 else "k_rollout")),
                 "launch_ms": per_launch_ms,
                 "algorithmic_bytes_per_env_step": bytes_per_step, "env_steps_per_launch": n * steps_per_launch_avg,
             },

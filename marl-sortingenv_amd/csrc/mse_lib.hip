@@ -1458,10 +1458,18 @@ int mse_create_indexed(mse_env **out, const mse_config *cfg, int64_t n_envs, int
     }
     // the byte-packed integer draw needs every prefix sum below 128; larger batches draw in literal fp64
     h->literal = cfg->literal_choice != 0 || cfg->input_batch_size > 127;
-    // rollout kernel: the pipelined one (dynamics + observer waves) pays off while a one-lane-per-env grid
-    // leaves the SIMDs under two waves each; 0 = decide by size, 1 = always, 2 = never
+    // rollout kernel: the multi-role kernels serve 256 envs per workgroup, one workgroup per CU (their LDS image is
+    // the whole CU's), so they pay off exactly while the batch fits the chip in one round: n <= 256 x CUs (65 536 on
+    // an MI355X).  Beyond that a one-lane-per-env grid already gives every SIMD several waves and wins (measured at
+    // 131 072 envs: 16.5 G env-steps/s against 15.9).  0 = decide by size, 1 / 3 = always, 2 = never
+    int cus = 256;
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0)
+            cus = prop.multiProcessorCount;
+    }
     h->pipelined = cfg->rollout_pipeline == 1 || cfg->rollout_pipeline == 3 ||
-                   (cfg->rollout_pipeline == 0 && n_envs <= 131072);
+                   (cfg->rollout_pipeline == 0 && n_envs <= (int64_t)kPoEnvs * cus);
     {
         // draws per step are bounded by the mis-sorted units of the two stations a mode leaves unboosted at the
         // lowest accuracy the noise allows; the ring kernel needs that bound <= kRingMaxPerStep

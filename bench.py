@@ -89,6 +89,9 @@ def main():
     ap.add_argument("--no-outputs", action="store_true", help="diagnostic only: skip obs/mask writes (INVALID as a result)")
     ap.add_argument("--mode", default="rollout", choices=["rollout", "step"],
                     help="rollout: fused mse_rollout launches (headline); step: mse_sample_actions + mse_step per step")
+    ap.add_argument("--sort-policy", default="frozen", choices=["frozen", "rule"],
+                    help="Env_2_Pressing only: the sorting decisions - a frozen random policy (per-env Bernoulli(1/2) drawn "
+                         "once with seed 1234: BASELINE.json configs[2]) or the reference's sorting_rules()")
     ap.add_argument("--pipeline", type=int, default=0, choices=[0, 1, 2, 3],
                     help="mse_config.rollout_pipeline: 0 by size (default), 1 two-role, 2 one lane per env, 3 three-role ring")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -125,12 +128,16 @@ def main():
     chunk = max(1, args.chunk)
     buf = env.alloc_rollout(chunk, obs=not args.no_outputs, mask=not args.no_outputs)
     stream = torch.cuda.current_stream(dev)
+    sort_mode = None
+    if args.kind == "press" and args.sort_policy == "frozen":
+        g = torch.Generator(device="cpu").manual_seed(1234 + rank)
+        sort_mode = (torch.rand(n, generator=g) < 0.5).to(torch.int32).to(dev)
 
     def run(n_steps, events=None):
         if args.mode == "step":
             for _ in range(n_steps):
                 act = env.sample_actions(policy_seed=2024)
-                env.step(act)
+                env.step(act, sort_mode=sort_mode)
             return
         # HIP events on the launch stream bracket the run of launches as a whole: they are queued back to back (the
         # host is far ahead of a 70 us kernel), so elapsed / launches is the kernel's duration plus the ~1.5 us
@@ -141,9 +148,9 @@ def main():
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(stream)
         for _ in range(n_full):
-            env.rollout(chunk, policy_seed=2024, buffers=buf)
+            env.rollout(chunk, policy_seed=2024, buffers=buf, sort_mode=sort_mode)
         if tail > 0:
-            env.rollout(tail, policy_seed=2024, buffers=buf)
+            env.rollout(tail, policy_seed=2024, buffers=buf, sort_mode=sort_mode)
         if events is not None:
             e1.record(stream)
             events.append((n_full + (1 if tail else 0), n_steps, e0, e1))
@@ -196,7 +203,8 @@ def main():
             "config": {
                 "workload": f"Env_3_Monolith random-policy rollout, {n} envs per GPU" if args.kind == "mono"
                             else f"{args.kind} random-policy rollout, {n} envs per GPU",
-                "env_kind": args.kind, "envs_per_gpu": n, "global_envs": n * world, "max_steps": args.max_steps,
+                "env_kind": args.kind, **({"sorting_policy": args.sort_policy} if args.kind == "press" else {}),
+                "envs_per_gpu": n, "global_envs": n * world, "max_steps": args.max_steps,
                 "balesize": 200, "noise_sorting": args.noise, "policy": "on-device masked-uniform, seed 2024",
                 "steps_per_launch": chunk, "outputs": "none (diagnostic)" if args.no_outputs else
                 "obs f32[K,N,D], mask u8[K,N,A], action i32, reward f32, done u8 per step",

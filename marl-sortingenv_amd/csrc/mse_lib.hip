@@ -80,6 +80,22 @@ __device__ __forceinline__ void load_tables_to_lds(uint32_t *dst, const uint32_t
     __syncthreads();
 }
 
+// Streaming 16-byte store of an output piece: the rollout buffers are written once and read by someone else much
+// later, while the state planes (9 MB at 65 536 envs) are read back by the very next launch - keep the outputs from
+// pushing them out of L2.
+typedef float nt_f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int nt_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_stream(float4 *p, const float4 &v)
+{
+    nt_f32x4 x = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(x, reinterpret_cast<nt_f32x4 *>(p));
+}
+__device__ __forceinline__ void store_stream(uint4 *p, const uint4 &v)
+{
+    nt_u32x4 x = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(x, reinterpret_cast<nt_u32x4 *>(p));
+}
+
 // Each WAVE stages the 64 rows of its own lanes and streams them out itself: the rows of one wave are a
 // contiguous, 16-byte aligned run of the output (64 x 116 B for obs), and the LDS executes one wave's
 // instructions in order, so no workgroup barrier is needed (the first profile showed 36 % of wave time
@@ -124,8 +140,8 @@ __device__ __forceinline__ void stage_and_store(uint8_t *lds_base, int mask_offs
 #pragma unroll
             for (int j = 0; j <= NFULL; ++j) buf[j] = src[lane + 64 * j]; // the last one may run past the tile: unused
 #pragma unroll
-            for (int j = 0; j < NFULL; ++j) dst[lane + 64 * j] = buf[j];
-            if (NTAIL > 0 && lane < NTAIL) dst[lane + 64 * NFULL] = buf[NFULL];
+            for (int j = 0; j < NFULL; ++j) store_stream(dst + lane + 64 * j, buf[j]);
+            if (NTAIL > 0 && lane < NTAIL) store_stream(dst + lane + 64 * NFULL, buf[NFULL]);
         } else {
             for (int q = lane; q < total; q += 64) g[q] = lobs[q];
         }
@@ -139,8 +155,8 @@ __device__ __forceinline__ void stage_and_store(uint8_t *lds_base, int mask_offs
             uint4 *dst = reinterpret_cast<uint4 *>(g);
             const uint4 b0 = src[lane];
             const uint4 b1 = src[lane + 64]; // may run past the tile: unused
-            if (lane < NQ) dst[lane] = b0;
-            if (NQ > 64 && lane + 64 < NQ) dst[lane + 64] = b1;
+            if (lane < NQ) store_stream(dst + lane, b0);
+            if (NQ > 64 && lane + 64 < NQ) store_stream(dst + lane + 64, b1);
         } else {
             for (int q = lane; q < total; q += 64) g[q] = lmask[q];
         }

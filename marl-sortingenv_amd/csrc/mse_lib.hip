@@ -316,9 +316,9 @@ __global__ __launch_bounds__(kBlock) void k_rollout(Params P, uint4 *__restrict_
             mbits = action_mask_bits<KIND>(e, P);
 #endif
             cur_mask = mbits; // what the next step's policy sees
-            if (actions_out != nullptr) actions_out[(long long)s * P.n + i] = a;
-            if (reward_out != nullptr) reward_out[(long long)s * P.n + i] = (float)r.reward;
-            if (done_out != nullptr) done_out[(long long)s * P.n + i] = (uint8_t)r.done;
+            if (actions_out != nullptr) __builtin_nontemporal_store(a, &actions_out[(long long)s * P.n + i]);
+            if (reward_out != nullptr) __builtin_nontemporal_store((float)r.reward, &reward_out[(long long)s * P.n + i]);
+            if (done_out != nullptr) __builtin_nontemporal_store((uint8_t)r.done, &done_out[(long long)s * P.n + i]);
         }
         stage_and_store<KIND>(lds, LdsLayout<KIND>::obs_bytes, o, mbits, obs_out ? obs_out + srow * D : nullptr,
                               mask_out ? mask_out + srow * A : nullptr, n_valid, tid);
@@ -495,9 +495,9 @@ __global__ __launch_bounds__(kPoThreads) void k_rollout_po(Params P, uint4 *__re
                     int k2[4];
                     (void)env_observe<KIND, true>(rs, P, tb, k2, o);
                 }
-                if (actions_out != nullptr) actions_out[(long long)s * P.n + i] = a;
-                if (reward_out != nullptr) reward_out[(long long)s * P.n + i] = (float)r.reward;
-                if (done_out != nullptr) done_out[(long long)s * P.n + i] = (uint8_t)r.done;
+                if (actions_out != nullptr) __builtin_nontemporal_store(a, &actions_out[(long long)s * P.n + i]);
+                if (reward_out != nullptr) __builtin_nontemporal_store((float)r.reward, &reward_out[(long long)s * P.n + i]);
+                if (done_out != nullptr) __builtin_nontemporal_store((uint8_t)r.done, &done_out[(long long)s * P.n + i]);
             }
             const long long srow = (long long)s * P.n + row0;
             stage_and_store<KIND>(lds, L::obs_bytes, o, mbits, obs_out ? obs_out + srow * D : nullptr,
@@ -793,9 +793,9 @@ __global__ __launch_bounds__(kRingThreads) void k_rollout_ring(Params P, uint4 *
                     int k2[4];
                     (void)env_observe<KIND, true>(rs, P, tb, k2, o);
                 }
-                if (actions_out != nullptr) actions_out[(long long)s * P.n + i] = a;
-                if (reward_out != nullptr) reward_out[(long long)s * P.n + i] = (float)r.reward;
-                if (done_out != nullptr) done_out[(long long)s * P.n + i] = (uint8_t)r.done;
+                if (actions_out != nullptr) __builtin_nontemporal_store(a, &actions_out[(long long)s * P.n + i]);
+                if (reward_out != nullptr) __builtin_nontemporal_store((float)r.reward, &reward_out[(long long)s * P.n + i]);
+                if (done_out != nullptr) __builtin_nontemporal_store((uint8_t)r.done, &done_out[(long long)s * P.n + i]);
             }
             MSE_TL(tl, 1);
             const long long srow = (long long)s * P.n + row0;

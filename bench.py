@@ -1,6 +1,6 @@
 """bench.py -- env-steps/sec of the batched HIP step engine (BASELINE.json metric).
 
-    python bench.py --gpus 1 --steps 200 --warmup 20
+    python bench.py --gpus 1 --steps 256 --warmup 64
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -10,8 +10,8 @@ reward, auto-reset) and obs / mask / reward / done / action are written to HBM f
 Workload (config.workload): Env_3_Monolith, 65 536 envs per GPU, max_steps 200, balesize 200,
 noise 0.0, env i seeded with its global index (weak scaling: per-GPU work is fixed; no data-path
 collective - env instances never interact).  Steps are issued as fused rollout launches of
-`--chunk` steps each (state stays in registers inside a launch); `--chunk 1` gives one launch
-per step.  Inputs (state, seeds) are resident in HBM before the timed region.
+`--chunk` steps each (default 64; state stays in registers inside a launch); `--chunk 1` gives one
+launch per step.  Inputs (state, seeds) are resident in HBM before the timed region.
 
 Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement").
 """
@@ -71,7 +71,7 @@ def measured_traffic(args, n, chunk):
             t = json.load(f)
     except OSError:
         return None
-    if (args.kind, n, chunk, args.noise, args.mode, args.no_outputs) == ("mono", 65536, 16, 0.0, "rollout", False):
+    if (args.kind, n, chunk, args.noise, args.mode, args.no_outputs) == ("mono", 65536, int(t.get("steps_per_launch", 16)), 0.0, "rollout", False):
         return t.get("hbm_bytes_per_launch")
     return None
 
@@ -79,11 +79,12 @@ def measured_traffic(args, n, chunk):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=208)
-    ap.add_argument("--warmup", type=int, default=32)
+    ap.add_argument("--steps", type=int, default=256)
+    ap.add_argument("--warmup", type=int, default=64)
     ap.add_argument("--envs", type=int, default=65536, help="envs per GPU")
     ap.add_argument("--kind", default="mono", choices=["mono", "press", "sort"])
-    ap.add_argument("--chunk", type=int, default=16, help="steps fused per rollout launch")
+    ap.add_argument("--chunk", type=int, default=64,
+                    help="steps fused per rollout launch (the rollout length n_steps of the collector; SB3's PPO default, which the reference trains with, is 2048; DESIGN.md section 6 tabulates 16 / 32 / 64 / 208)")
     ap.add_argument("--noise", type=float, default=0.0)
     ap.add_argument("--max-steps", type=int, default=200)
     ap.add_argument("--no-outputs", action="store_true", help="diagnostic only: skip obs/mask writes (INVALID as a result)")

@@ -3,7 +3,7 @@
 # one role compiled out (build/abl/libmse_{BASE,RING_NOO,RING_NOQ,NODRAW}.so; never shipped).
 OUT=gpurun_out/prof_roles; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
-A="--steps 64 --warmup 16 --no-cpu-baseline"
+A="--steps 256 --warmup 64 --no-cpu-baseline"
 for v in BASE RING_NOO RING_NOQ NODRAW; do
   export MSE_LIB_PATH=$PWD/build/abl/libmse_$v.so
   rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_BUSY_CYCLES --output-format csv -d $OUT/$v -- python bench.py $A > $OUT/$v.log 2>&1 || tail -3 $OUT/$v.log

@@ -1,6 +1,6 @@
 """bench.py -- env-steps/sec of the batched HIP step engine (BASELINE.json metric).
 
-    python bench.py --gpus 1 --steps 256 --warmup 64
+    python bench.py --gpus 1 --steps 1024 --warmup 128
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -79,8 +79,8 @@ def measured_traffic(args, n, chunk):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=256)
-    ap.add_argument("--warmup", type=int, default=64)
+    ap.add_argument("--steps", type=int, default=1024)
+    ap.add_argument("--warmup", type=int, default=128)
     ap.add_argument("--envs", type=int, default=65536, help="envs per GPU")
     ap.add_argument("--kind", default="mono", choices=["mono", "press", "sort"])
     ap.add_argument("--chunk", type=int, default=64,

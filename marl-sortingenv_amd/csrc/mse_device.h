@@ -1191,16 +1191,28 @@ struct BaleRef {
 // env_super.py:626-640 press_action_rules = check_press_status (:642-659) then use_press (:722-769)
 __device__ __forceinline__ void press_action_rules(Env &e, const Params &P, int press_action, const BaleRef &bales)
 {
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-        if (e.timer[p] > 0) {
-            e.timer[p] -= 1;
-            if (e.timer[p] == 0) {
-                if (P.track_bales) press_bale(bales.cell(e.pmat[p]), P, e.pn[p], e.q100[p]);
-                e.pmat[p] = 0xFF;
-                e.pn[p] = 0;
-                e.q100[p] = 0;
-            }
+    // check_press_status: both timers tick; a press that reaches 0 books its bale.  A finishing press is rare per
+    // lane but near-certain per wave, so the ledger update is written once (for press 0 if it finished, else press
+    // 1) and the case of both finishing in the same step takes a second, almost never executed, copy.
+    const bool fin0 = e.timer[0] == 1, fin1 = e.timer[1] == 1;
+    e.timer[0] -= e.timer[0] > 0 ? 1 : 0;
+    e.timer[1] -= e.timer[1] > 0 ? 1 : 0;
+    if (fin0 || fin1) {
+        const int first = fin0 ? 0 : 1;
+        if (P.track_bales)
+            press_bale(bales.cell(first ? e.pmat[1] : e.pmat[0]), P, first ? e.pn[1] : e.pn[0], first ? e.q100[1] : e.q100[0]);
+        if (__builtin_expect(fin0 && fin1, 0)) { // press 0 was booked above (reference order: press 1, then 2)
+            if (P.track_bales) press_bale(bales.cell(e.pmat[1]), P, e.pn[1], e.q100[1]);
+        }
+        if (fin0) {
+            e.pmat[0] = 0xFF;
+            e.pn[0] = 0;
+            e.q100[0] = 0;
+        }
+        if (fin1) {
+            e.pmat[1] = 0xFF;
+            e.pn[1] = 0;
+            e.q100[1] = 0;
         }
     }
     if (press_action == 0) return;

@@ -18,7 +18,8 @@ import marl_sortingenv_amd as M  # noqa: E402
 lib = os.path.abspath(sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "build/abl/libmse_timeline.so"))
 kind = sys.argv[2] if len(sys.argv) > 2 else "mono"
 n = int(sys.argv[3]) if len(sys.argv) > 3 else 65536
-K, launches = 16, 13
+K = int(sys.argv[4]) if len(sys.argv) > 4 else 16
+launches = 13
 env = M.BatchedSortingEnv(kind=kind, num_envs=n, device=0, base_seed=0, max_steps=200, noise_sorting=0.0,
                           balesize=200, library=lib)
 buf = env.alloc_rollout(K)

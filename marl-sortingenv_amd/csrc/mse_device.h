@@ -859,6 +859,74 @@ __device__ __forceinline__ void draw_units_ring(RngRing &rng, uint32_t &C, int &
 #endif
 }
 
+// The RNG lane's production loop (k_rollout_ring): `count` PCG64 steps, the upper 32 output bits of each stored
+// at LDS row (w & 63) of the lane's ring column (lane_addr, 64 KiB-aligned ring).  The same 21-instruction LCG step
+// and 7-instruction output as draw_units_local, an address in two instructions and three of loop control: 34 per
+// output against 38 + 7 scalar from the structured C++ loop.  Products and carries live in v[112:121].
+__device__ __forceinline__ void ring_produce(Pcg &g, uint32_t &w, uint32_t count, uint32_t lane_addr)
+{
+    uint32_t s0 = (uint32_t)g.s_lo, s1 = (uint32_t)(g.s_lo >> 32), s2 = (uint32_t)g.s_hi, s3 = (uint32_t)(g.s_hi >> 32);
+    const uint32_t i0 = (uint32_t)g.i_lo, i1 = (uint32_t)(g.i_lo >> 32), i2 = (uint32_t)g.i_hi, i3 = (uint32_t)(g.i_hi >> 32);
+    const uint32_t m0 = 0x9FCCF645u, m1 = 0x4385DF64u, m2 = 0x1FC65DA4u, m3 = 0x2360ED05u, kMask = 0xFC00u;
+    uint32_t w10 = w << 10, left = count;
+    uint32_t t0, t1, t2, t3, x, y;
+    uint64_t sv, cm, dm;
+    asm volatile(
+        "s_mov_b64 %[sv], exec\n\t"
+        "v_cmp_ne_u32 vcc, 0, %[left]\n\t"
+        "s_and_b64 exec, exec, vcc\n\t"
+        "s_cbranch_execz 3f\n\t"
+        "v_mov_b32 v121, 0\n"
+        "1:\n\t"
+        "v_mad_u64_u32 v[112:113], %[dm], %[s0], %[m0], 0\n\t"
+        "v_mul_lo_u32 %[t3], %[s3], %[m0]\n\t"
+        "v_mul_lo_u32 %[t0], %[s0], %[m3]\n\t"
+        "v_mov_b32 v120, v113\n\t"
+        "v_mad_u64_u32 v[114:115], %[dm], %[s0], %[m1], v[120:121]\n\t"
+        "v_mul_lo_u32 %[t1], %[s1], %[m2]\n\t"
+        "v_mul_lo_u32 %[t2], %[s2], %[m1]\n\t"
+        "v_mov_b32 v120, v114\n\t"
+        "v_mad_u64_u32 v[116:117], %[dm], %[s1], %[m0], v[120:121]\n\t"
+        "v_mov_b32 v120, v115\n\t"
+        "v_mad_u64_u32 v[118:119], %[dm], %[s0], %[m2], v[120:121]\n\t"
+        "v_add3_u32 %[t0], %[t0], %[t1], %[t2]\n\t"
+        "v_mad_u64_u32 v[118:119], %[dm], %[s1], %[m1], v[118:119]\n\t"
+        "v_mov_b32 v120, v117\n\t"
+        "v_mad_u64_u32 v[118:119], %[dm], %[s2], %[m0], v[118:119]\n\t"
+        "v_add_u32 %[t0], %[t0], %[t3]\n\t"
+        "v_lshl_add_u64 v[118:119], v[118:119], 0, v[120:121]\n\t"
+        "v_add_co_u32 %[s0], vcc, v112, %[i0]\n\t"
+        "v_addc_co_u32 %[s1], vcc, v116, %[i1], vcc\n\t"
+        "v_add_u32 %[t0], %[t0], v119\n\t"
+        "v_addc_co_u32 %[s2], vcc, v118, %[i2], vcc\n\t"
+        "v_addc_co_u32 %[s3], vcc, %[t0], %[i3], vcc\n\t"
+        "v_xor_b32 %[x], %[s0], %[s2]\n\t"
+        "v_xor_b32 %[y], %[s1], %[s3]\n\t"
+        "v_lshrrev_b32 %[t1], 26, %[s3]\n\t"
+        "v_cmp_gt_i32 vcc, 0, %[s3]\n\t"
+        "v_and_or_b32 %[t0], %[w10], %[mask], %[lane]\n\t"
+        "v_cndmask_b32 %[t2], %[x], %[y], vcc\n\t"
+        "v_cndmask_b32 %[t3], %[y], %[x], vcc\n\t"
+        "v_add_u32 %[left], -1, %[left]\n\t"
+        "v_alignbit_b32 %[t2], %[t2], %[t3], %[t1]\n\t"
+        "v_add_u32 %[w10], 0x400, %[w10]\n\t"
+        "v_cmp_ne_u32_e64 %[cm], 0, %[left]\n\t"
+        "ds_write_b32 %[t0], %[t2]\n\t"
+        "s_and_b64 exec, exec, %[cm]\n\t"
+        "s_cbranch_execnz 1b\n"
+        "3:\n\t"
+        "s_mov_b64 exec, %[sv]"
+        : [s0] "+v"(s0), [s1] "+v"(s1), [s2] "+v"(s2), [s3] "+v"(s3), [w10] "+v"(w10), [left] "+v"(left), [t0] "=&v"(t0),
+          [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [x] "=&v"(x), [y] "=&v"(y), [sv] "=&s"(sv), [cm] "=&s"(cm),
+          [dm] "=&s"(dm)
+        : [i0] "v"(i0), [i1] "v"(i1), [i2] "v"(i2), [i3] "v"(i3), [m0] "s"(m0), [m1] "s"(m1), [m2] "s"(m2), [m3] "s"(m3),
+          [mask] "s"(kMask), [lane] "v"(lane_addr)
+        : "vcc", "memory", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121");
+    g.s_lo = (uint64_t)s0 | ((uint64_t)s1 << 32);
+    g.s_hi = (uint64_t)s2 | ((uint64_t)s3 << 32);
+    w += count;
+}
+
 // The same hand-placed loop for a lane that advances its own generator (one-lane-per-env kernels: k_step,
 // k_rollout).  Per draw: the 128-bit LCG step on 32-bit limbs (6 v_mad_u64_u32 + 4 v_mul_lo_u32, the {carry, 0}
 // addends through one scratch pair), the upper half of the XSL-RR output, and the decision of draw_units_ring;

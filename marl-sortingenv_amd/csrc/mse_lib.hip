@@ -602,7 +602,7 @@ __global__ __launch_bounds__(kRingThreads) void k_rollout_ring(Params P, uint4 *
             g.i_lo = (uint64_t)b.x | ((uint64_t)b.y << 32);
             g.i_hi = (uint64_t)b.z | ((uint64_t)b.w << 32);
         }
-        uint32_t *base = lring + el;
+        const uint32_t ring_lane_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)(lring + el);
         // Production is demand-driven.  After B_s the lane knows r_s (outputs consumed through step s); the
         // outputs of step s+1 (< r_s + worst) are in place already, those of step s+2 (< r_s + 2 worst) must be
         // before B_{s+1}: that is `need`.  `cap` is how far a lane may run ahead: the ring's 64 slots, but
@@ -630,12 +630,7 @@ __global__ __launch_bounds__(kRingThreads) void k_rollout_ring(Params P, uint4 *
                 if (__builtin_amdgcn_ballot_w64(deficit >= cand) != 0ull) M = cand;
             }
             const uint32_t room = cap > w ? cap - w : 0u;
-            const uint32_t target = w + (M < room ? M : room);
-            while (w < target) {
-                pcg_advance(g);
-                base[(w & (uint32_t)(kRingDepth - 1)) * (uint32_t)kPoEnvs] = pcg_output_hi32(g);
-                w += 1u;
-            }
+            ring_produce(g, w, M < room ? M : room, ring_lane_addr);
             MSE_TLB(tl, 0);
             lds_barrier_all(); // s == -1: B_init (first outputs are in place); else B_s
             MSE_TLB(tl, 1);

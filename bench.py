@@ -13,6 +13,12 @@ collective - env instances never interact).  Steps are issued as fused rollout l
 `--chunk` steps each (default 64; state stays in registers inside a launch); `--chunk 1` gives one
 launch per step.  Inputs (state, seeds) are resident in HBM before the timed region.
 
+A pass = exactly `--steps` steps.  One pass of a short run (the driver's `--steps 20` is one 85 us launch) is
+shorter than the two device synchronisations that bracket it, so the timed region holds `reps` passes issued back
+to back (state advancing, `reps` reported; default: as many as reach ~2048 steps, `--reps 1` for a single
+pass) and value / ms_per_step are per step of that region; `single_pass_ms` is the median of individually
+bracketed passes, sync overhead included, for comparison.
+
 Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement").
 """
 from __future__ import annotations
@@ -28,6 +34,9 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+# SQ_ACTIVE_INST_VALU / (SQ_WAVE_CYCLES / 3 waves per SIMD) of k_rollout_ring, profiles/r01/v6_summary.json (re-measured
+# per round in profiles/rNN/): the share of cycles in which a SIMD's VALU is issuing
+VALU_ISSUE_RATIO = 0.77
 
 
 def cpu_baseline(kind: str, max_steps: int, noise: float, balesize: int, budget_s: float = 12.0):
@@ -61,19 +70,28 @@ def cpu_baseline(kind: str, max_steps: int, noise: float, balesize: int, budget_
     }
 
 
-def measured_traffic(args, n, chunk):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/r01/traffic.json: FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate --pmc runs); only quoted for the
-    exact workload it was collected on, else null."""
-    path = os.path.join(ROOT, "profiles", "r01", "traffic.json")
-    try:
-        with open(path) as f:
-            t = json.load(f)
-    except OSError:
+def measured_traffic(args, n, steps_per_launch):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/r02/traffic.json,
+    else r01's: FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate --pmc runs, tools/prof_traffic.sh); only quoted for the
+    exact workload and steps per launch it was collected on, else null."""
+    if (args.kind, n, args.noise, args.mode, args.no_outputs) != ("mono", 65536, 0.0, "rollout", False):
         return None
-    if (args.kind, n, chunk, args.noise, args.mode, args.no_outputs) == ("mono", 65536, int(t.get("steps_per_launch", 16)), 0.0, "rollout", False):
-        return t.get("hbm_bytes_per_launch")
+    for rnd in ("r02", "r01"):
+        try:
+            with open(os.path.join(ROOT, "profiles", rnd, "traffic.json")) as f:
+                t = json.load(f)
+        except OSError:
+            continue
+        entries = t.get("entries") or [t]
+        for e in entries:
+            if int(e.get("steps_per_launch", -1)) == int(steps_per_launch) and e.get("policy", "random") == args.policy:
+                return e.get("hbm_bytes_per_launch")
     return None
+
+
+# What one launch of K fused steps must move per env (SURVEY 8d's inventory, DESIGN.md section 6): every step's
+# outputs and action, the state once per launch.  {kind: (state read, state written, outputs + action per step)}
+FUSED_BYTES = {"mono": (130, 114, 143 + 4), "sort": (130 + 37, 114 + 21, 52 + 4 + 1 + 4), "press": (130, 114, 64 + 11 + 4 + 1 + 4)}
 
 
 def main():
@@ -95,6 +113,11 @@ def main():
                          "once with seed 1234: BASELINE.json configs[2]) or the reference's sorting_rules()")
     ap.add_argument("--pipeline", type=int, default=0, choices=[0, 1, 2, 3],
                     help="mse_config.rollout_pipeline: 0 by size (default), 1 two-role, 2 one lane per env, 3 three-role ring")
+    ap.add_argument("--reps", type=int, default=0,
+                    help="passes of --steps steps inside the timed region (0 = as many as reach ~2048 steps)")
+    ap.add_argument("--policy", default="random", choices=["random", "mlp"],
+                    help="random: the on-device masked-uniform policy (headline); mlp: the reference's actor-critic MLP "
+                         "evaluated inside the rollout kernel (MaskablePPO-shaped collection, BASELINE.json configs[3])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
     args = ap.parse_args()
@@ -134,7 +157,24 @@ def main():
         g = torch.Generator(device="cpu").manual_seed(1234 + rank)
         sort_mode = (torch.rand(n, generator=g) < 0.5).to(torch.int32).to(dev)
 
+    collector = None
+    if args.policy == "mlp":
+        collector = M.FusedPolicyRollout(env, M.MlpPolicy.random_init(env.obs_dim, env.num_actions, seed=7, device=dev), chunk)
+
     def run(n_steps, events=None):
+        if collector is not None:
+            n_full, tail = n_steps // chunk, n_steps % chunk
+            if events is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(stream)
+            for _ in range(n_full):
+                collector.collect(chunk)
+            if tail > 0:
+                collector.collect(tail)
+            if events is not None:
+                e1.record(stream)
+                events.append((n_full + (1 if tail else 0), n_steps, e0, e1))
+            return
         if args.mode == "step":
             for _ in range(n_steps):
                 act = env.sample_actions(policy_seed=2024)
@@ -160,13 +200,23 @@ def main():
         if world > 1:
             dist.barrier()
 
+    reps = args.reps if args.reps > 0 else max(1, -(-2048 // args.steps))
     run(args.warmup)
     torch.cuda.synchronize(dev)
+    # individually bracketed passes first (sync on both sides of each: what a caller who waits per pass sees)
+    singles = []
+    for _ in range(min(reps, 9)):
+        t1 = time.perf_counter()
+        run(args.steps)
+        torch.cuda.synchronize(dev)
+        singles.append(time.perf_counter() - t1)
+    singles.sort()
     barrier()
     torch.cuda.synchronize(dev)
     events = []
     t0 = time.perf_counter()
-    run(args.steps, events)
+    for _ in range(reps):
+        run(args.steps, events)
     torch.cuda.synchronize(dev)
     barrier()
     torch.cuda.synchronize(dev)
@@ -178,26 +228,34 @@ def main():
     elapsed = float(t.item())
 
     # dominant kernel: the rollout kernel.  HIP events on the launch stream around the launches of the timed region
-    bytes_per_step = env.algorithmic_bytes_per_step
+    # (first event of the first pass to the last event of the last: the passes are queued back to back)
+    bytes_contract = env.algorithmic_bytes_per_step  # charges a state round trip to EVERY step
     if events:
         launches = sum(c for c, _, _, _ in events)
         steps_timed = sum(k for _, k, _, _ in events)
-        total_ms = sum(a.elapsed_time(b) for _, _, a, b in events)
+        total_ms = events[0][2].elapsed_time(events[-1][3])
         per_launch_ms = total_ms / max(1, launches)
-        achieved = bytes_per_step * n * steps_timed / (total_ms * 1e-3) / 1e9
         steps_per_launch_avg = steps_timed / max(1, launches)
+        st_r, st_w, per_step = FUSED_BYTES[args.kind]
+        noise_r, noise_w = (32, 16) if args.noise > 0 else (0, 0)
+        # bytes a fused launch must move per env-step: outputs + action every step, state once per launch
+        policy_out = 8 if args.policy == "mlp" else 0  # + log-probability and value f32 per step
+        fused_bytes = per_step + policy_out + (st_r + st_w + noise_r + noise_w) / steps_per_launch_avg
+        achieved = fused_bytes * n * steps_timed / (total_ms * 1e-3) / 1e9
+        achieved_contract = bytes_contract * n * steps_timed / (total_ms * 1e-3) / 1e9
     else:  # --mode step: two kernels per step, no single dominant launch to quote
-        per_launch_ms, achieved, steps_per_launch_avg = None, None, 1
+        per_launch_ms, achieved, achieved_contract, steps_per_launch_avg, fused_bytes = None, None, None, 1, None
     assert env.error_count() == 0
 
     if rank == 0:
         out = {
             "metric": "env-steps/sec (random policy) Env_3_Monolith @65k envs" if args.kind == "mono" and n == 65536
                       else f"env-steps/sec (random policy) {args.kind} @{n} envs",
-            "value": n * world * args.steps / elapsed,
+            "value": n * world * args.steps * reps / elapsed,
             "unit": "env-steps/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed * 1e3 / args.steps,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "reps": reps,
+            "ms_per_step": elapsed * 1e3 / (args.steps * reps),
+            "single_pass_ms": singles[len(singles) // 2] * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "int32+f64 (integer state/masks, fp64 rewards, f32 observations)",
             "data": "synthetic",
@@ -206,21 +264,33 @@ def main():
                             else f"{args.kind} random-policy rollout, {n} envs per GPU",
                 "env_kind": args.kind, **({"sorting_policy": args.sort_policy} if args.kind == "press" else {}),
                 "envs_per_gpu": n, "global_envs": n * world, "max_steps": args.max_steps,
-                "balesize": 200, "noise_sorting": args.noise, "policy": "on-device masked-uniform, seed 2024",
-                "steps_per_launch": chunk, "outputs": "none (diagnostic)" if args.no_outputs else
+                "balesize": 200, "noise_sorting": args.noise,
+                "policy": "on-device masked-uniform, seed 2024" if args.policy == "random" else
+                          "actor-critic MLP 2x32 tanh (random-init weights) with masked categorical sampling, inside the rollout kernel",
+                "steps_per_launch": min(chunk, args.steps), "outputs": "none (diagnostic)" if args.no_outputs else
                 "obs f32[K,N,D], mask u8[K,N,A], action i32, reward f32, done u8 per step",
                 "parallelism": f"env-index sharding x{world}, no data-path collective" +
                                (f" (REHEARSAL: {world} ranks on {n_dev} GPU)" if rehearsal else ""),
             },
             "roofline": {
-                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                # priced against HBM (the contract's roofline for this byte/integer path); what actually limits the
+                # kernel at this size is VALU issue: SQ_ACTIVE_INST_VALU / (SQ_WAVE_CYCLES / waves per SIMD) from the
+                # committed PMC pass (profiles/)
+                "bound": "valu-issue", "priced_against": "hbm",
+                "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": None if achieved is None else achieved / HBM_PEAK_GBPS,
-                "traffic": measured_traffic(args, n, chunk) if args.steps % chunk == 0 else None,
+                "fused_bytes_per_env_step": fused_bytes,
+                "traffic": measured_traffic(args, n, steps_per_launch_avg) if float(steps_per_launch_avg).is_integer() else None,
                 "kernel": ("k_sample + k_step" if args.mode == "step" else
+                           "k_rollout_policy" if args.policy == "mlp" else
                            {1: "k_rollout_po", 2: "k_rollout", 3: "k_rollout_ring"}.get(
                                args.pipeline, "k_rollout_ring" if n <= 65536 else "k_rollout")),
-                "launch_ms": per_launch_ms,
-                "algorithmic_bytes_per_env_step": bytes_per_step, "env_steps_per_launch": n * steps_per_launch_avg,
+                "launch_ms": per_launch_ms, "env_steps_per_launch": n * steps_per_launch_avg,
+                # SURVEY 8d's per-step contract (state read + written EVERY step): a fused launch does not move those
+                # bytes, so this figure can pass 1.0 on long launches of large batches - kept for comparison only
+                "contract_bytes_per_env_step": bytes_contract, "achieved_contract": achieved_contract,
+                "frac_contract": None if achieved_contract is None else achieved_contract / HBM_PEAK_GBPS,
+                "valu_issue_ratio": VALU_ISSUE_RATIO,
             },
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MSE_VERSION 100 /* 0.1.0 */
+#define MSE_VERSION 200 /* 0.2.0 */
 
 typedef enum mse_status {
     MSE_OK = 0,
@@ -50,6 +50,13 @@ typedef enum mse_env_kind { MSE_ENV_SORT = 1, MSE_ENV_PRESS = 2, MSE_ENV_MONO = 
 /* mse_rollout only: act with the reference's rule-based policy (mode='rule_based', env_monolith.py:166-184:
  * sorting_rules() env_super.py:469-482 + check_container_level() :689-720) instead of the random one */
 #define MSE_ROLLOUT_RULE_BASED  4u
+/* with MSE_STEP_UNMASKED on Env_3: test the press action's validity AFTER sort_material instead of at decode time -
+ * what Env_3_Monolith.step(action=None, mode='random', use_action_masking=False) does (env_monolith.py:245-253:
+ * sanitize_press_action runs in the "apply" section; an invalid action still skips press_action_rules) */
+#define MSE_STEP_SANITIZE_LATE  8u
+/* mse_model_actions only: leave the sorting / the pressing decision to an agent (no draw, that part is 0) */
+#define MSE_MODEL_NO_SORT_DRAW  16u
+#define MSE_MODEL_NO_PRESS_DRAW 32u
 
 /* POD copy of the reference's config.yml plus the env constructor arguments
  * (env_super.py:25-137 reads the same keys; env_monolith.py:22-23 ctor). */
@@ -161,10 +168,14 @@ int mse_action_masks(mse_env *env, uint8_t *mask_out, void *stream);
  * state is not changed; feed the agent's decisions to the next mse_step / mse_rollout as sort_mode_dev.
  * Defined for every env kind (the sorting view of the state one flow update ahead). */
 int mse_sort_agent_obs(mse_env *env, float *obs13_out, void *stream);
+/* The same preview for a pressing agent: get_press_obs() after the coming step's flow update, which is what
+ * Env_3_Monolith.step(mode='model') hands its press_agent (env_monolith.py:198-210).  obs16_out f32[N, 16]. */
+int mse_press_agent_obs(mse_env *env, float *obs16_out, void *stream);
 
-/* K fused steps with the on-device masked-uniform random policy (the reference's
- * mode='random' with masking, env_monolith.py:152-158, with a counter-based policy stream
- * instead of the global np.random).  State stays in registers across the K steps.
+/* K fused steps with the on-device random policy (the reference's mode='random', env_monolith.py:152-164, with a
+ * counter-based policy stream instead of the global np.random): uniform over the set bits of action_masks(), or -
+ * with MSE_STEP_UNMASKED - over the whole action space, the step sanitising what it gets (add MSE_STEP_SANITIZE_LATE
+ * on Env_3 for the reference's exact mode='random' sequencing).  State stays in registers across the K steps.
  * Outputs are step-major: actions_out i32[K,N], obs_out f32[K,N,D], reward_out f32[K,N],
  * done_out u8[K,N], mask_out u8[K,N,A]; any of them may be NULL.  Needs auto_reset=1.
  *   sort_mode_dev i32[N] or NULL: Env_2's frozen per-env sorting decision (NULL = rule). */
@@ -182,14 +193,62 @@ int mse_rule_actions(mse_env *env, int32_t *action_out, void *stream);
 /* State export / import in a fixed record layout (tests, checkpoint/resume, dashboard trace):
  *   ints  i64[N, MSE_SNAP_INTS]  (column map: MSE_SNAP_* below)
  *   dbls  f64[N, 4]              accuracy_belt
- *   rng   u64[N, 18]             {state_hi,state_lo,inc_hi,inc_lo,has_uint32,uinteger} x
- *                                {rng (seed+99), rng_noise (seed+4), rng_pressing (seed+3)}
+ *   rng   u64[N, 24]             {state_hi,state_lo,inc_hi,inc_lo,has_uint32,uinteger} x
+ *                                {rng (seed+99), rng_noise (seed+4), rng_pressing (seed+3), rng_sorting (seed+2)}
  * Replaces reading/writing the attributes of Env_Super (env_super.py:52-137). */
 #define MSE_SNAP_INTS 71
+#define MSE_SNAP_RNG_WORDS 24
 int mse_get_state(mse_env *env, int64_t *ints_out, double *dbls_out, uint64_t *rng_out, void *stream);
 int mse_set_state(mse_env *env, const int64_t *ints_in, const double *dbls_in, const uint64_t *rng_in, void *stream);
 
-/* Number of out-of-range actions seen so far (synchronises the device). */
+/* Env_3_Monolith.step(action=None, mode='model') with no agents assigned (env_monolith.py:186-221): per env the
+ * sorting decision rng_sorting.choice([0, 1]) (:195) and the press action rng_pressing.choice(flatnonzero(
+ * press_action_masks())) (:214-217), or rng_pressing.choice(11) with MSE_STEP_UNMASKED (:219), NumPy-exact (buffered
+ * Lemire draws on the env's own PCG64 streams, which advance).  action_out i32[N] = mode * 11 + press action; step
+ * it with mse_step and flags WITHOUT MSE_STEP_UNMASKED: the reference applies a mode='model' action through
+ * press_action_rules without sanitising it (env_monolith.py:254-257).  flags: MSE_STEP_UNMASKED,
+ * MSE_MODEL_NO_SORT_DRAW, MSE_MODEL_NO_PRESS_DRAW (an assigned agent decides that part).  Env_3 handles only. */
+int mse_model_actions(mse_env *env, uint32_t flags, int32_t *action_out, void *stream);
+
+/* Opt-in trace of ONE env: what the reference appends per step to its Python ledgers - reward_data
+ * (env_super.py:402-408, 928-946), press_actions_per_timestep (:631-637, 730-736; env_monolith.py:136;
+ * env_2_press.py:131) and the press_bale calls behind bale_count (:661-687) - which the dashboard reads
+ * (utils/plotting.py:32-48).  Between mse_trace_begin and mse_trace_end every mse_step appends one record
+ * f64[MSE_TRACE_COLS] for env `env_index` to records_dev (caller-owned device memory, `capacity` records; a step
+ * beyond the capacity fails with MSE_ERR_INVALID_ARGUMENT; mse_rollout is refused while a trace is attached).
+ * The values are those of the state _log_step_data sees: after the step, before any auto-reset.  Unbounded
+ * per-env ledgers are not kept for all N lanes (DESIGN.md "Not carried per lane"); this is the one-env form. */
+#define MSE_TRACE_COLS       40
+#define MSE_TRACE_ACTION      0 /* the flat action the step applied (Env_1: the sensor mode)                     */
+#define MSE_TRACE_R_SORT      1 /* _log_step_data(r_sort, r_press): env_1_sort.py:141,151; env_2_press.py:152,162; */
+#define MSE_TRACE_R_PRESS     2 /*                                  env_monolith.py:271,282                         */
+#define MSE_TRACE_SETTING     3 /* sensor_current_setting                                                         */
+#define MSE_TRACE_BELT        4 /* [4] current_material_belt (Belt_Occupancy, Belt_Proportions derive from it)    */
+#define MSE_TRACE_CONT_TRUE   8 /* [4] container A..D true                                                        */
+#define MSE_TRACE_CONT_FALSE 12 /* [4] container A..D false                                                       */
+#define MSE_TRACE_CONT_E     16
+#define MSE_TRACE_N_LOG      17 /* entries appended to press_actions_per_timestep this step (0..2)                */
+#define MSE_TRACE_LOG        18 /* [2][2] {code, material}: code 0 no-op, 1|2 press started, 111|222 busy/invalid */
+#define MSE_TRACE_N_BALE     22 /* press_bale calls this step (0..2)                                              */
+#define MSE_TRACE_BALE       23 /* [2][3] {material 0..4, amount n, int(q*100)} in the reference's call order      */
+#define MSE_TRACE_DONE       29
+#define MSE_TRACE_STEP       30 /* current_step after the step                                                    */
+#define MSE_TRACE_INTERNAL   31 /* Env_1: the press action sampled inside the env (env_1_sort.py:125)             */
+#define MSE_TRACE_REWARD     32 /* the step's reward (f64)                                                        */
+#define MSE_TRACE_ACC_BELT   33 /* [4] accuracy_belt after the step (the next step's accuracy_sorter)             */
+int mse_trace_begin(mse_env *env, int64_t env_index, double *records_dev, int64_t capacity);
+int mse_trace_end(mse_env *env, int64_t *n_records_out);
+
+/* The step counter t of the on-device policy stream (word = f(policy seed, global env index, t); every mse_step
+ * advances it by 1, every mse_rollout by k_steps).  It is host-side handle state, not part of the state record:
+ * a checkpoint that must reproduce an on-device-policy rollout saves it with mse_get_state's record and restores
+ * it after mse_set_state. */
+int mse_get_policy_step(const mse_env *env, uint64_t *t_out);
+int mse_set_policy_step(mse_env *env, uint64_t t);
+
+/* Number of out-of-range actions (mse_step) and of unreachable values handed to mse_set_state (stage vectors that
+ * are no generator output, accuracies outside [clip(baseline [+ boost] - noise), 1]) seen so far; synchronises
+ * the device. */
 int mse_error_count(mse_env *env, uint64_t *count_out);
 
 /* Algorithmic HBM bytes per env-step used for the roofline figure. */

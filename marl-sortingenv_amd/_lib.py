@@ -7,8 +7,11 @@ import os
 from .build import LIB_PATH
 
 MSE_ENV_SORT, MSE_ENV_PRESS, MSE_ENV_MONO = 1, 2, 3
-MSE_STEP_UNMASKED, MSE_STEP_CHECK_OVERFLOW, MSE_ROLLOUT_RULE_BASED = 1, 2, 4
+MSE_STEP_UNMASKED, MSE_STEP_CHECK_OVERFLOW, MSE_ROLLOUT_RULE_BASED, MSE_STEP_SANITIZE_LATE = 1, 2, 4, 8
+MSE_MODEL_NO_SORT_DRAW, MSE_MODEL_NO_PRESS_DRAW = 16, 32
 MSE_SNAP_INTS = 71
+MSE_SNAP_RNG_WORDS = 24  # rng, rng_noise, rng_pressing, rng_sorting x {state_hi, state_lo, inc_hi, inc_lo, has_uint32, uinteger}
+MSE_TRACE_COLS = 40
 
 EXPORTS = [
     "mse_version", "mse_last_error", "mse_status_string", "mse_config_default", "mse_create",
@@ -16,6 +19,7 @@ EXPORTS = [
     "mse_step", "mse_action_masks", "mse_rollout", "mse_sample_actions", "mse_rule_actions", "mse_get_state", "mse_set_state",
     "mse_error_count", "mse_algorithmic_bytes_per_step", "mse_tie_window",
     "mse_sort_agent_obs", "mse_policy_num_weights", "mse_policy_create", "mse_policy_destroy", "mse_policy_forward",
+    "mse_get_policy_step", "mse_set_policy_step", "mse_model_actions", "mse_trace_begin", "mse_trace_end", "mse_press_agent_obs",
 ]
 
 _other_libs: dict = {}
@@ -89,6 +93,7 @@ def load_library(path: str | None = None) -> C.CDLL:
     L.mse_step.argtypes = [vp, vp, vp, u32, vp, vp, vp, vp, vp, vp, vp]
     L.mse_action_masks.argtypes = [vp, vp, vp]
     L.mse_sort_agent_obs.argtypes = [vp, vp, vp]
+    L.mse_press_agent_obs.argtypes = [vp, vp, vp]
     L.mse_rollout.argtypes = [vp, i32, u64, vp, u32, vp, vp, vp, vp, vp, vp]
     L.mse_sample_actions.argtypes = [vp, u64, vp, vp]
     L.mse_rule_actions.argtypes = [vp, vp, vp]
@@ -96,6 +101,11 @@ def load_library(path: str | None = None) -> C.CDLL:
     L.mse_set_state.argtypes = [vp, vp, vp, vp, vp]
     L.mse_error_count.argtypes = [vp, C.POINTER(u64)]
     L.mse_algorithmic_bytes_per_step.argtypes = [vp]
+    L.mse_get_policy_step.argtypes = [vp, C.POINTER(u64)]
+    L.mse_set_policy_step.argtypes = [vp, u64]
+    L.mse_model_actions.argtypes = [vp, u32, vp, vp]
+    L.mse_trace_begin.argtypes = [vp, i64, vp, i64]
+    L.mse_trace_end.argtypes = [vp, C.POINTER(i64)]
     for name in EXPORTS:
         getattr(L, name)  # AttributeError if the library does not export what include/mse.h declares
     L.mse_tie_window.restype = u32

@@ -13,8 +13,8 @@ from typing import Optional
 import torch
 
 from . import _lib
-from ._lib import (MSE_ROLLOUT_RULE_BASED, MSE_SNAP_INTS, MSE_STEP_CHECK_OVERFLOW, MSE_STEP_UNMASKED, check,
-                   load_library)
+from ._lib import (MSE_MODEL_NO_PRESS_DRAW, MSE_MODEL_NO_SORT_DRAW, MSE_ROLLOUT_RULE_BASED, MSE_SNAP_INTS, MSE_SNAP_RNG_WORDS,
+                   MSE_STEP_CHECK_OVERFLOW, MSE_STEP_SANITIZE_LATE, MSE_STEP_UNMASKED, MSE_TRACE_COLS, check, load_library)
 from .config import NUM_ACTIONS, OBS_DIM, SortingEnvConfig
 
 
@@ -56,6 +56,7 @@ class BatchedSortingEnv:
         check(self.L.mse_create_indexed(C.byref(h), C.byref(self._cfg_struct), self.num_envs, dev_index,
                                         self.index_offset))
         self._h = h
+        self._trace_buf, self._trace_n = None, 0
         n, dev = self.num_envs, self.device
         self.obs = torch.zeros((n, self.obs_dim), dtype=torch.float32, device=dev)
         self.reward = torch.zeros((n,), dtype=torch.float32, device=dev)
@@ -102,20 +103,24 @@ class BatchedSortingEnv:
 
     def step(self, actions: torch.Tensor, sort_mode: Optional[torch.Tensor] = None,
              use_action_masking: bool = True, check_overflow: bool = False, want_reward64: bool = False,
-             want_terminal_obs: bool = False):
+             want_terminal_obs: bool = False, sanitize_late: bool = False):
         """One transition of all N envs.  Returns (obs, reward, done, mask): views of buffers that
-        the next step overwrites."""
+        the next step overwrites.  sanitize_late (Env_3 without masking): validate the press action after
+        sort_material, as the reference's mode='random' does (MSE_STEP_SANITIZE_LATE)."""
         if actions.dtype != torch.int32 or not actions.is_contiguous() or actions.device != self.device:
             actions = actions.to(device=self.device, dtype=torch.int32).contiguous()
         if actions.numel() != self.num_envs:
             raise ValueError("actions must have one entry per env")
         if sort_mode is not None:
             sort_mode = sort_mode.to(device=self.device, dtype=torch.int32).contiguous()
-        flags = (0 if use_action_masking else MSE_STEP_UNMASKED) | (MSE_STEP_CHECK_OVERFLOW if check_overflow else 0)
+        flags = (0 if use_action_masking else MSE_STEP_UNMASKED) | (MSE_STEP_CHECK_OVERFLOW if check_overflow else 0) | \
+                (MSE_STEP_SANITIZE_LATE if sanitize_late else 0)
         with torch.cuda.device(self.device):
             check(self.L.mse_step(self._h, _ptr(actions), _ptr(sort_mode), flags, _ptr(self.obs), _ptr(self.reward),
                                   _ptr(self.reward64) if want_reward64 else None, _ptr(self.done), _ptr(self.mask),
                                   _ptr(self.terminal_obs) if want_terminal_obs else None, self._stream()))
+        if self._trace_buf is not None:
+            self._trace_n += 1
         return self.obs, self.reward, self.done, self.mask
 
     def action_masks(self) -> torch.Tensor:
@@ -132,6 +137,14 @@ class BatchedSortingEnv:
             check(self.L.mse_sort_agent_obs(self._h, _ptr(out), self._stream()))
         return out
 
+    def press_agent_obs(self) -> torch.Tensor:
+        """f32[N, 16]: get_press_obs() after the coming step's flow update - what Env_3_Monolith.step(mode='model')
+        hands its press_agent (env_monolith.py:198-210)."""
+        out = torch.empty((self.num_envs, 16), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            check(self.L.mse_press_agent_obs(self._h, _ptr(out), self._stream()))
+        return out
+
     def sample_actions(self, policy_seed: int = 2024) -> torch.Tensor:
         out = torch.empty((self.num_envs,), dtype=torch.int32, device=self.device)
         with torch.cuda.device(self.device):
@@ -144,6 +157,49 @@ class BatchedSortingEnv:
         with torch.cuda.device(self.device):
             check(self.L.mse_rule_actions(self._h, _ptr(out), self._stream()))
         return out
+
+    def model_actions(self, use_action_masking: bool = True, draw_sort: bool = True, draw_press: bool = True) -> torch.Tensor:
+        """Env_3_Monolith.step(mode='model') with no agents assigned (env_monolith.py:186-221): the env's own
+        rng_sorting / rng_pressing draws, NumPy-exact; the streams drawn from advance (draw_sort / draw_press = False:
+        an assigned agent decides that part, it comes back as 0).  Step the result with masking semantics."""
+        out = torch.empty((self.num_envs,), dtype=torch.int32, device=self.device)
+        flags = (0 if use_action_masking else MSE_STEP_UNMASKED) | (0 if draw_sort else MSE_MODEL_NO_SORT_DRAW) | \
+                (0 if draw_press else MSE_MODEL_NO_PRESS_DRAW)
+        with torch.cuda.device(self.device):
+            check(self.L.mse_model_actions(self._h, flags, _ptr(out), self._stream()))
+        return out
+
+    # ---- opt-in trace of one env (the reference's dashboard ledgers) ---------------------------------
+    def trace_begin(self, env_index: int = 0, capacity: int = 4096) -> None:
+        """From now on every step() appends one record f64[MSE_TRACE_COLS] for env `env_index` (mse_trace_begin)."""
+        self._trace_buf = torch.zeros((int(capacity), MSE_TRACE_COLS), dtype=torch.float64, device=self.device)
+        self._trace_n = 0
+        check(self.L.mse_trace_begin(self._h, int(env_index), _ptr(self._trace_buf), int(capacity)))
+
+    def trace_records(self) -> torch.Tensor:
+        """The records written so far (synchronises the stream); the trace stays attached."""
+        if getattr(self, "_trace_buf", None) is None:
+            return torch.zeros((0, MSE_TRACE_COLS), dtype=torch.float64, device=self.device)
+        torch.cuda.current_stream(self.device).synchronize()
+        return self._trace_buf[: self._trace_n]
+
+    def trace_end(self) -> torch.Tensor:
+        """Detaches the trace and returns its records f64[n, MSE_TRACE_COLS]."""
+        rec = self.trace_records().clone()
+        check(self.L.mse_trace_end(self._h, None))
+        self._trace_buf = None
+        return rec
+
+    # ---- policy-stream counter (host-side handle state, see include/mse.h) ---------------------------
+    @property
+    def policy_step(self) -> int:
+        v = C.c_uint64(0)
+        check(self.L.mse_get_policy_step(self._h, C.byref(v)))
+        return int(v.value)
+
+    @policy_step.setter
+    def policy_step(self, t: int) -> None:
+        check(self.L.mse_set_policy_step(self._h, int(t)))
 
     def alloc_rollout(self, k_steps: int, obs=True, mask=True, actions=True, reward=True, done=True):
         n, dev, K = self.num_envs, self.device, int(k_steps)
@@ -165,6 +221,8 @@ class BatchedSortingEnv:
         if sort_mode is not None:
             sort_mode = sort_mode.to(device=self.device, dtype=torch.int32).contiguous()
         flags = (0 if use_action_masking else MSE_STEP_UNMASKED) | (MSE_STEP_CHECK_OVERFLOW if check_overflow else 0)
+        if not use_action_masking and self.kind == "mono" and policy == "random":
+            flags |= MSE_STEP_SANITIZE_LATE  # the reference's mode='random' sequencing (env_monolith.py:245-253)
         if policy == "rule_based":
             flags |= MSE_ROLLOUT_RULE_BASED
         elif policy != "random":
@@ -181,7 +239,7 @@ class BatchedSortingEnv:
         n, dev = self.num_envs, self.device
         ints = torch.empty((n, MSE_SNAP_INTS), dtype=torch.int64, device=dev)
         dbls = torch.empty((n, 4), dtype=torch.float64, device=dev)
-        rng = torch.empty((n, 18), dtype=torch.int64, device=dev)  # raw u64 words
+        rng = torch.empty((n, MSE_SNAP_RNG_WORDS), dtype=torch.int64, device=dev)  # raw u64 words
         with torch.cuda.device(self.device):
             check(self.L.mse_get_state(self._h, _ptr(ints), _ptr(dbls), _ptr(rng), self._stream()))
         return ints, dbls, rng
@@ -192,6 +250,13 @@ class BatchedSortingEnv:
         ints, dbls, rng = prep(ints, torch.int64), prep(dbls, torch.float64), prep(rng, torch.int64)
         with torch.cuda.device(self.device):
             check(self.L.mse_set_state(self._h, _ptr(ints), _ptr(dbls), _ptr(rng), self._stream()))
+
+    def refresh_outputs(self):
+        """Rewrites self.obs / self.mask from the current state (after set_state): a reset that resets no env."""
+        none = torch.zeros((self.num_envs,), dtype=torch.uint8, device=self.device)
+        with torch.cuda.device(self.device):
+            check(self.L.mse_reset(self._h, None, _ptr(none), _ptr(self.obs), _ptr(self.mask), self._stream()))
+        return self.obs, self.mask
 
     def error_count(self) -> int:
         v = C.c_uint64(0)

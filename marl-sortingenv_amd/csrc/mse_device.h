@@ -19,6 +19,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "mse_policy_stream.h"
+
 namespace mse {
 
 constexpr int kBlock = 256;             // threads per workgroup = 4 wavefronts of 64
@@ -41,6 +43,9 @@ enum Plane : int {
     PL_PRESS_INC,
     PL_BALE0,          // bale ledger summary per material {count, sum, last_size, last_q}; cold
     PL_BALE1, PL_BALE2, PL_BALE3, PL_BALE4,
+    PL_SORTRNG_STATE,  // rng_sorting (seed+2): only Env_3's mode='model' fallback draws from it (k_model_actions); cold
+    PL_SORTRNG_INC,
+    PL_SORTRNG_AUX,    // {uinteger, has_uint32, 0, 0} of rng_sorting's 32-bit buffer
     PL_COUNT
 };
 
@@ -81,6 +86,8 @@ struct Params {
     uint32_t qi_down[4]; // bit q set: int((q / 100.0) * 100.0) == q - 1  (press_bale's stored quality)
     int rem_thr_units;   // floor(bale_standard_size * bale_remainder_threshold)
     int ring_worst; // most sort_material draws one step can make with this config (k_rollout_ring flow control)
+    double acc_floor[4]; // lowest accuracy_belt[m] the config can produce: clip(baseline [+ boost] - noise).  ring_worst
+                         // is derived from it, so mse_set_state counts anything below as an error (mse_error_count)
 };
 
 // ------------------------------------------------------------------------------------------
@@ -251,22 +258,6 @@ __device__ __forceinline__ uint64_t mix64(uint64_t z)
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
     return z ^ (z >> 31);
-}
-
-// counter-based random policy word for (policy seed, global env index, step counter): murmur3's 32-bit
-// finaliser over an odd-constant combination of the three (10 instructions; a 64-bit splitmix cost 25)
-__device__ __forceinline__ uint32_t policy_u32(uint64_t seed, uint64_t env_index, uint64_t t)
-{
-    const uint32_t s32 = (uint32_t)seed ^ ((uint32_t)(seed >> 32) * 0x85EBCA6Bu);
-    const uint32_t g32 = (uint32_t)env_index ^ ((uint32_t)(env_index >> 32) * 0xC2B2AE35u);
-    const uint32_t t32 = (uint32_t)t ^ ((uint32_t)(t >> 32) * 0x27D4EB2Fu);
-    uint32_t h = s32 + g32 * 0x9E3779B1u + t32 * 0x85EBCA77u;
-    h ^= h >> 16;
-    h *= 0x85EBCA6Bu;
-    h ^= h >> 13;
-    h *= 0xC2B2AE35u;
-    h ^= h >> 16;
-    return h;
 }
 
 // index of the k-th (0-based) set bit of `bits`
@@ -745,9 +736,6 @@ struct RngCounted {
 template <bool LITERAL, class RNG>
 __device__ __forceinline__ void draw_units(RNG &rng, uint32_t &C, int &rem)
 {
-#ifdef MSE_ABL_NODRAW
-    rem = 0;
-#endif
     // env_super.py:557-559 breaks out when the pool is empty.  That cannot happen: a station starts its
     // draws with its own false units in the pool (T >= rem) and every draw lowers both T and rem by one.
     while (rem > 0) {
@@ -806,9 +794,6 @@ __device__ __forceinline__ void draw_units(RNG &rng, uint32_t &C, int &rem)
 
 __device__ __forceinline__ void draw_units_ring(RngRing &rng, uint32_t &C, int &rem)
 {
-#ifdef MSE_ABL_NODRAW
-    rem = 0;
-#endif
 #ifdef MSE_TIMELINE
     rng.tl->mark(2); // everything of sort_material outside the draw loops
 #endif
@@ -934,9 +919,6 @@ __device__ __forceinline__ void ring_produce(Pcg &g, uint32_t &w, uint32_t count
 // sort_material redoes the step literally when one shows.  Products and carries live in v[112:123].
 __device__ __forceinline__ void draw_units_local(Pcg &g, uint32_t &C, int &rem, uint32_t &f_min, uint32_t &f_max)
 {
-#ifdef MSE_ABL_NODRAW
-    rem = 0;
-#endif
     uint32_t T = C >> 24;
     const uint32_t n_draws = (uint32_t)rem;
     const uint32_t T_end = T - n_draws;
@@ -1201,6 +1183,23 @@ __device__ __forceinline__ void divmod_small(int amount, int S, float inv_S, int
     }
 }
 
+// int(q * 100) of press_bale (env_super.py:664): q100 minus a bit of P.qi_down
+__device__ __forceinline__ uint32_t bale_quality_int(const Params &P, int q100)
+{
+    const uint32_t w = (uint32_t)q100 >> 5;
+    const uint32_t word = w == 0 ? P.qi_down[0] : (w == 1 ? P.qi_down[1] : (w == 2 ? P.qi_down[2] : P.qi_down[3]));
+    return (uint32_t)q100 - ((word >> ((uint32_t)q100 & 31u)) & 1u);
+}
+
+// What one step appends to the reference's per-env Python ledgers (opt-in trace of ONE env, mse_trace_begin):
+// press_actions_per_timestep entries (env_super.py:631-637,730-736; env_monolith.py:136; env_2_press.py:131) and
+// the press_bale calls (env_super.py:661-687).  Only the TRACE instantiation of k_step fills it.
+struct Ledger {
+    int n_log, code[2], mat[2];        // code 0 no-op, 1|2 press started, 111|222 busy / invalid; mat 0..4 or -1
+    int n_bale, bmat[2], bn[2], bq[2]; // finished presses in the reference's order: material, amount, int(q*100)
+    int internal;                      // Env_1: the press action the env sampled itself (env_1_sort.py:125)
+};
+
 // env_super.py:661-687 press_bale on the O(1) ledger summary {count, sum, last_size, last_q}.
 // The reference's three floating-point expressions here are functions of small integers and are evaluated as
 // such (a finishing press is a per-lane rarity but a per-wave certainty, so this path runs almost every step):
@@ -1212,9 +1211,7 @@ __device__ __forceinline__ void divmod_small(int amount, int S, float inv_S, int
 __device__ __forceinline__ void press_bale(uint4 *cell, const Params &P, int n, int q100)
 {
     uint4 c = *cell;
-    const uint32_t w = (uint32_t)q100 >> 5;
-    const uint32_t word = w == 0 ? P.qi_down[0] : (w == 1 ? P.qi_down[1] : (w == 2 ? P.qi_down[2] : P.qi_down[3]));
-    const uint32_t qi = (uint32_t)q100 - ((word >> ((uint32_t)q100 & 31u)) & 1u);
+    const uint32_t qi = bale_quality_int(P, q100);
     const uint32_t S = (uint32_t)P.balesize;
     int full_i, rem_i;
     if (__builtin_expect(n < (1 << 24), 1)) divmod_small(n, P.balesize, P.inv_balesize, full_i, rem_i);
@@ -1257,7 +1254,9 @@ struct BaleRef {
 };
 
 // env_super.py:626-640 press_action_rules = check_press_status (:642-659) then use_press (:722-769)
-__device__ __forceinline__ void press_action_rules(Env &e, const Params &P, int press_action, const BaleRef &bales)
+template <bool TRACE = false>
+__device__ __forceinline__ void press_action_rules(Env &e, const Params &P, int press_action, const BaleRef &bales,
+                                                   Ledger *lg = nullptr)
 {
     // check_press_status: both timers tick; a press that reaches 0 books its bale.  A finishing press is rare per
     // lane but near-certain per wave, so the ledger update is written once (for press 0 if it finished, else press
@@ -1267,6 +1266,16 @@ __device__ __forceinline__ void press_action_rules(Env &e, const Params &P, int 
     e.timer[1] -= e.timer[1] > 0 ? 1 : 0;
     if (fin0 || fin1) {
         const int first = fin0 ? 0 : 1;
+        if (TRACE) {
+            for (int p = 0; p < 2; ++p) {
+                if (p == 0 ? fin0 : fin1) {
+                    lg->bmat[lg->n_bale] = e.pmat[p];
+                    lg->bn[lg->n_bale] = e.pn[p];
+                    lg->bq[lg->n_bale] = (int)bale_quality_int(P, e.q100[p]);
+                    lg->n_bale += 1;
+                }
+            }
+        }
         if (P.track_bales)
             press_bale(bales.cell(first ? e.pmat[1] : e.pmat[0]), P, first ? e.pn[1] : e.pn[0], first ? e.q100[1] : e.q100[0]);
         if (__builtin_expect(fin0 && fin1, 0)) { // press 0 was booked above (reference order: press 1, then 2)
@@ -1283,10 +1292,22 @@ __device__ __forceinline__ void press_action_rules(Env &e, const Params &P, int 
             e.q100[1] = 0;
         }
     }
-    if (press_action == 0) return;
+    if (press_action == 0) {
+        if (TRACE) { // (0, None): env_super.py:629-637
+            lg->code[lg->n_log] = 0;
+            lg->mat[lg->n_log] = -1;
+            lg->n_log += 1;
+        }
+        return;
+    }
     int p, mat;
     decode_press_action(press_action, p, mat);
     const int tm = p ? e.timer[1] : e.timer[0];
+    if (TRACE) { // busy: (111 | 222, material) env_super.py:725-733; else the action tuple :736
+        lg->code[lg->n_log] = tm > 0 ? (p ? 222 : 111) : p + 1;
+        lg->mat[lg->n_log] = mat;
+        lg->n_log += 1;
+    }
     if (tm > 0) return; // busy: no state change (env_super.py:725-733)
     int total = e.ce, tru = 0; // container E: quality 0 (env_super.py:755-757)
 #pragma unroll
@@ -1512,12 +1533,14 @@ __device__ __forceinline__ PenaltyClass classify_levels(const int lvl[5], const 
 
 // env_1_sort.py:97-154 / env_2_press.py:88-165 / env_monolith.py:109-284 up to (not including) the reward
 // and observation, plus the state side effects of calculate_press_reward and the step counter.
-template <int KIND, bool NOISE, bool LITERAL, class RNG>
+template <int KIND, bool NOISE, bool LITERAL, class RNG, bool TRACE = false>
 __device__ __forceinline__ void env_dynamics(Env &e, RNG &rng, const Params &P, const Tables &tb, int action,
-                                             int sort_mode_in, uint32_t flags, const BaleRef &bales, Snap &sn)
+                                             int sort_mode_in, uint32_t flags, const BaleRef &bales, Snap &sn,
+                                             Ledger *lg = nullptr)
 {
     const bool unmasked = (flags & 1u) != 0;
     const bool check_overflow = (flags & 2u) != 0;
+    const bool late = (flags & 8u) != 0; // MSE_STEP_SANITIZE_LATE: Env_3 mode='random' without masking
 
     // input_action_rules draws rng_input.integers(60,81) and discards it (env_super.py:911-922, :433);
     // that stream is never observed, so it is not carried.
@@ -1538,26 +1561,47 @@ __device__ __forceinline__ void env_dynamics(Env &e, RNG &rng, const Params &P, 
         press_action = action - 11 * sort_mode;
         // env_monolith.py:132-138: validated at decode time (pre-sort levels); an invalid action
         // skips press_action_rules altogether, so the timers do not tick this step
-        if (unmasked && !press_action_valid(e, P, press_action)) run_press_rules = false;
+        if (unmasked && !late && !press_action_valid(e, P, press_action)) {
+            run_press_rules = false;
+            if (TRACE) { // invalid_info (111 | 222, name): env_monolith.py:132-136
+                lg->code[lg->n_log] = press_action > 5 ? 222 : 111;
+                lg->mat[lg->n_log] = (press_action - 1) % 5;
+                lg->n_log += 1;
+            }
+        }
     }
 
     double acc_sorter[4];
     update_accuracy<NOISE>(e, tb.cst, tb.acc, sort_mode, acc_sorter);
     MSE_TL(e.tl, 1);
-#ifndef MSE_ABL_NOSORT
     sort_material<LITERAL>(e, rng, sorting_word, acc_sorter);
-#endif
     MSE_TL(e.tl, 2);
 
     if (KIND == 1) {
         press_action = sample_masked_press_action(e, P); // env_1_sort.py:125-126 (mask before the tick)
+        if (TRACE) lg->internal = press_action;
     } else if (KIND == 2) {
         // env_2_press.py:125-138: validated against post-sort levels; the timers still tick
-        if (unmasked && !press_action_valid(e, P, press_action)) press_action = 0;
+        if (unmasked && !press_action_valid(e, P, press_action)) {
+            if (TRACE) { // env_2_press.py:127-131: the invalid entry, then press_action_rules((None, None)) logs a no-op
+                lg->code[lg->n_log] = press_action > 5 ? 222 : 111;
+                lg->mat[lg->n_log] = (press_action - 1) % 5;
+                lg->n_log += 1;
+            }
+            press_action = 0;
+        }
+    } else if (KIND == 3 && unmasked && late) {
+        // env_monolith.py:245-253 (mode='random' without masking): sanitised after the sort; invalid -> no tick either
+        if (!press_action_valid(e, P, press_action)) {
+            run_press_rules = false;
+            if (TRACE) {
+                lg->code[lg->n_log] = press_action > 5 ? 222 : 111;
+                lg->mat[lg->n_log] = (press_action - 1) % 5;
+                lg->n_log += 1;
+            }
+        }
     }
-#ifndef MSE_ABL_NOPRESS
-    if (run_press_rules) press_action_rules(e, P, press_action, bales);
-#endif
+    if (run_press_rules) press_action_rules<TRACE>(e, P, press_action, bales, lg);
     MSE_TL(e.tl, 3);
 
     // snapshot for the observer
@@ -1599,6 +1643,7 @@ __device__ __forceinline__ void env_dynamics(Env &e, RNG &rng, const Params &P, 
 struct StepResult {
     double reward;
     int done;
+    double r_sort, r_press; // the two arguments of _log_step_data (env_super.py:928): read by the trace only
 };
 
 // Rewards (env_super.py:963-1080) and observation (env_super.py:306-359) of a snapshot; k[] returns the
@@ -1645,12 +1690,8 @@ __device__ __forceinline__ StepResult env_observe(const Snap &sn, const Params &
 
     // ---- purity: four fp64 divisions (they also cover batch A's LDS latency) ----------------------
     // env_super.py:771-791; round(true/total, 2) in hundredths, [101] = empty container
-#ifdef MSE_ABL_NOREWARD
-    k[0] = k[1] = k[2] = k[3] = 101;
-#else
 #pragma unroll
     for (int m = 0; m < 4; ++m) k[m] = lvl[m] > 0 ? purity_hundredths(sn.ct[m], lvl[m]) : 101;
-#endif
 
     // ---- batch B: reads keyed by the purities -------------------------------------------------------
     float pdiff_f[4] = {0.f, 0.f, 0.f, 0.f};
@@ -1689,10 +1730,6 @@ __device__ __forceinline__ StepResult env_observe(const Snap &sn, const Params &
             rp = v < -1.0 ? -1.0 : (v > 1.0 ? 1.0 : v);
         }
     }
-#ifdef MSE_ABL_NOREWARD
-    rp = 0.0;
-    tanh_v = 0.0;
-#endif
 
     // ---- observation (env_super.py:306-359) ---------------------------------------------------------
     if (KIND != 2) {
@@ -1724,8 +1761,14 @@ __device__ __forceinline__ StepResult env_observe(const Snap &sn, const Params &
     StepResult r;
     r.done = sn.done;
     r.reward = KIND == 1 ? tanh_v : (KIND == 2 ? rp : tanh_v + rp);
+    r.r_sort = KIND == 2 ? 0.0 : tanh_v; // env_1_sort.py:151, env_2_press.py:162, env_monolith.py:282
+    r.r_press = KIND == 1 ? 0.0 : rp;
     // env_super.py:900-905 + the variants' early return: the overflow penalty replaces the rewards
-    if (__builtin_expect(sn.overflowed != 0, 0)) r.reward = tb.cst[CST_OVERFLOW_PEN];
+    if (__builtin_expect(sn.overflowed != 0, 0)) {
+        r.reward = tb.cst[CST_OVERFLOW_PEN];
+        r.r_sort = KIND == 3 ? r.reward / 2 : 0.0; // env_monolith.py:271; env_1_sort.py:141, env_2_press.py:152
+        r.r_press = KIND == 3 ? r.reward / 2 : r.reward;
+    }
     return r;
 }
 
@@ -1749,13 +1792,14 @@ __device__ __forceinline__ void snap_of_reset(Snap &sn, const double *cst)
 }
 
 // one env transition in one lane
-template <int KIND, bool NOISE, bool LITERAL>
+template <int KIND, bool NOISE, bool LITERAL, bool TRACE = false>
 __device__ __forceinline__ StepResult env_step(Env &e, const Params &P, const Tables &tb, int action, int sort_mode_in,
-                                               uint32_t flags, const BaleRef &bales, int k[4], float *o)
+                                               uint32_t flags, const BaleRef &bales, int k[4], float *o,
+                                               Ledger *lg = nullptr)
 {
     Snap sn;
     RngLocal rng{e.rng};
-    env_dynamics<KIND, NOISE, LITERAL>(e, rng, P, tb, action, sort_mode_in, flags, bales, sn);
+    env_dynamics<KIND, NOISE, LITERAL, RngLocal, TRACE>(e, rng, P, tb, action, sort_mode_in, flags, bales, sn, lg);
     return env_observe<KIND, NOISE>(sn, P, tb, k, o);
 }
 

@@ -177,27 +177,30 @@ __device__ __forceinline__ void auto_reset_env(Env &e, const Params &P, const Ta
 
 // action for the next step: the on-device masked-uniform policy (env_monolith.py:152-158 with masking) or,
 // with MSE_ROLLOUT_RULE_BASED, the reference's rule-based policy
+// pkey = mse_policy_key(policy seed, global env index): constant over a launch (mse_policy_stream.h)
 template <int KIND>
 __device__ __forceinline__ int policy_action(const Env &e, uint32_t cur, const Tables &tb, uint32_t flags,
-                                             uint64_t policy_seed, uint64_t env_index, uint64_t t)
+                                             uint32_t pkey, uint64_t t)
 {
     if (flags & MSE_ROLLOUT_RULE_BASED) {
         // stage id of the batch that will be on the belt: what update_environment moves from the input stage
         const int next_belt = e.st_in;
         return rule_based_action<KIND>(e, (int)tb.pat[next_belt * kPatStride + 2]);
     }
+    const uint32_t rr = mse_policy_word(pkey, t);
+    // without masking the random mode draws from the whole action space (env_monolith.py:159-162) and the step
+    // sanitises what it gets
+    if (flags & MSE_STEP_UNMASKED) return (int)(((uint64_t)rr * (uint32_t)Dims<KIND>::A) >> 32);
     const uint32_t cnt = (uint32_t)__popc(cur); // cur = action_masks() of the current state
-    uint32_t rr = policy_u32(policy_seed, env_index, t);
-#ifdef MSE_ABL_NOHASH
-    rr = ((uint32_t)env_index * 2654435761u) ^ ((uint32_t)t * 0x9E3779B9u);
-#endif
     return select_kth_bit(cur, (int)(((uint64_t)rr * cnt) >> 32));
 }
 
 // ==========================================================================================
 // kernels
 // ==========================================================================================
-template <int KIND, bool NOISE, bool LITERAL>
+// TRACE: the launch also appends one record (include/mse.h MSE_TRACE_*) for env `trace_env` to trace_rec - the
+// opt-in single-env trace behind the reference's dashboard ledgers (mse_trace_begin).
+template <int KIND, bool NOISE, bool LITERAL, bool TRACE = false>
 __global__ __launch_bounds__(kBlock) void k_step(Params P, uint4 *__restrict__ planes,
                                                  const uint32_t *__restrict__ table_image,
                                                  const int *__restrict__ action, const int *__restrict__ sort_mode,
@@ -205,7 +208,8 @@ __global__ __launch_bounds__(kBlock) void k_step(Params P, uint4 *__restrict__ p
                                                  float *__restrict__ reward_out, double *__restrict__ reward64_out,
                                                  uint8_t *__restrict__ done_out, uint8_t *__restrict__ mask_out,
                                                  float *__restrict__ terminal_obs_out,
-                                                 unsigned long long *__restrict__ err_count)
+                                                 unsigned long long *__restrict__ err_count,
+                                                 double *__restrict__ trace_rec = nullptr, long long trace_env = -1)
 {
     constexpr int D = Dims<KIND>::D, A = Dims<KIND>::A;
     uint8_t *lds = reinterpret_cast<uint8_t *>(mse_dyn_lds);
@@ -235,7 +239,42 @@ __global__ __launch_bounds__(kBlock) void k_step(Params P, uint4 *__restrict__ p
             a = 0;
         }
         int k[4];
-        StepResult r = env_step<KIND, NOISE, LITERAL>(e, P, tb, a, sm, flags, bales, k, o);
+        Ledger lg;
+        if (TRACE) {
+            lg.n_log = lg.n_bale = 0;
+            lg.internal = 0;
+            for (int q = 0; q < 2; ++q) lg.code[q] = lg.mat[q] = lg.bmat[q] = lg.bn[q] = lg.bq[q] = -1;
+        }
+        StepResult r = env_step<KIND, NOISE, LITERAL, TRACE>(e, P, tb, a, sm, flags, bales, k, o, &lg);
+        if (TRACE && i == trace_env) {
+            // the state _log_step_data sees: after the step, before any auto-reset
+            double *t = trace_rec;
+            const uint32_t bw = stage_word(e.st_belt, P);
+            t[MSE_TRACE_ACTION] = (double)a;
+            t[MSE_TRACE_R_SORT] = r.r_sort;
+            t[MSE_TRACE_R_PRESS] = r.r_press;
+            t[MSE_TRACE_SETTING] = (double)e.mode;
+            for (int m = 0; m < 4; ++m) {
+                t[MSE_TRACE_BELT + m] = (double)((bw >> (8 * m)) & 0xFFu);
+                t[MSE_TRACE_CONT_TRUE + m] = (double)e.ct[m];
+                t[MSE_TRACE_CONT_FALSE + m] = (double)e.cf[m];
+            }
+            t[MSE_TRACE_CONT_E] = (double)e.ce;
+            t[MSE_TRACE_N_LOG] = (double)lg.n_log;
+            t[MSE_TRACE_N_BALE] = (double)lg.n_bale;
+            for (int q = 0; q < 2; ++q) {
+                t[MSE_TRACE_LOG + 2 * q] = (double)lg.code[q];
+                t[MSE_TRACE_LOG + 2 * q + 1] = (double)lg.mat[q];
+                t[MSE_TRACE_BALE + 3 * q] = (double)lg.bmat[q];
+                t[MSE_TRACE_BALE + 3 * q + 1] = (double)lg.bn[q];
+                t[MSE_TRACE_BALE + 3 * q + 2] = (double)lg.bq[q];
+            }
+            t[MSE_TRACE_DONE] = (double)r.done;
+            t[MSE_TRACE_STEP] = (double)e.step;
+            t[MSE_TRACE_INTERNAL] = (double)lg.internal;
+            t[MSE_TRACE_REWARD] = r.reward;
+            for (int m = 0; m < 4; ++m) t[MSE_TRACE_ACC_BELT + m] = e.acc[m];
+        }
         if (r.done && P.auto_reset) {
             if (terminal_obs_out != nullptr) {
 #pragma unroll
@@ -297,24 +336,20 @@ __global__ __launch_bounds__(kBlock) void k_rollout(Params P, uint4 *__restrict_
 #pragma unroll
     for (int j = 0; j < D; ++j) o[j] = 0.0f;
     uint32_t cur_mask = live ? action_mask_bits<KIND>(e, P) : 1u;
+    const uint32_t pkey = mse_policy_key(policy_seed, (uint64_t)(P.index_offset + i));
 
     for (int s = 0; s < k_steps; ++s) {
         uint32_t mbits = 0;
         const long long srow = (long long)s * P.n + row0;
         if (live) {
-            int a = policy_action<KIND>(e, cur_mask, tb, flags, policy_seed, (uint64_t)(P.index_offset + i), policy_t0 + (uint64_t)s);
-#ifdef MSE_ABL_NOPOLICY
-            a = (int)(s & 1) * 11;
-#endif
+            int a = policy_action<KIND>(e, cur_mask, tb, flags, pkey, policy_t0 + (uint64_t)s);
             int k[4];
             StepResult r = env_step<KIND, NOISE, LITERAL>(e, P, tb, a, sm, flags, bales, k, o);
             if (__builtin_expect(r.done != 0, 0)) { // every env of a batch finishes its episode on the same step: rare, wave-uniform
                 auto_reset_env(e, P, tb, bales, k);
                 env_obs<KIND>(e, P, tb, k, o);
             }
-#ifndef MSE_ABL_NOMASK
             mbits = action_mask_bits<KIND>(e, P);
-#endif
             cur_mask = mbits; // what the next step's policy sees
             if (actions_out != nullptr) __builtin_nontemporal_store(a, &actions_out[(long long)s * P.n + i]);
             if (reward_out != nullptr) __builtin_nontemporal_store((float)r.reward, &reward_out[(long long)s * P.n + i]);
@@ -409,12 +444,12 @@ __global__ __launch_bounds__(kPoThreads) void k_rollout_po(Params P, uint4 *__re
         }
         __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): no load is outstanding inside the step loop
         uint32_t cur_mask = live ? action_mask_bits<KIND>(e, P) : 1u;
+        const uint32_t pkey = mse_policy_key(policy_seed, (uint64_t)(P.index_offset + i));
         for (int s = 0; s < k_steps; ++s) {
             // padding lanes (i >= n) hold no env: an all-zero PCG64 never leaves zero and would spin forever in
             // the Lemire rejection loop, so they only keep the barrier count
             if (live) {
-                const int a = policy_action<KIND>(e, cur_mask, tb, flags, policy_seed, (uint64_t)(P.index_offset + i),
-                                                  policy_t0 + (uint64_t)s);
+                const int a = policy_action<KIND>(e, cur_mask, tb, flags, pkey, policy_t0 + (uint64_t)s);
                 Snap sn;
                 RngLocal rng{e.rng};
                 env_dynamics<KIND, NOISE, LITERAL>(e, rng, P, tb, a, sm, flags, bales, sn);
@@ -617,9 +652,6 @@ __global__ __launch_bounds__(kRingThreads) void k_rollout_ring(Params P, uint4 *
         tl.start();
 #endif
         for (int s = -1; s < k_steps; ++s) {
-#ifdef MSE_ABL_RING_NOQ
-            w = cap > w ? cap : w;
-#endif
             // M = the largest shortfall in the wave (a 6-bit maximum found bit by bit with ballots, in SGPRs);
             // every lane then produces min(M, its room): a plain per-lane trip count for the loop below
             const uint32_t deficit = need > w ? need - w : 0u; // <= 2 worst <= 62
@@ -678,6 +710,7 @@ __global__ __launch_bounds__(kRingThreads) void k_rollout_ring(Params P, uint4 *
         rng.f_min = 0xFFFFFFFFu;
         rng.f_max = 0u;
         uint32_t cur_mask = live ? action_mask_bits<KIND>(e, P) : 1u;
+        const uint32_t pkey = mse_policy_key(policy_seed, (uint64_t)(P.index_offset + i));
         lpos[el] = 0;
         MSE_TL(edge, 1); // state load
         lds_barrier_all(); // B_init
@@ -687,8 +720,7 @@ __global__ __launch_bounds__(kRingThreads) void k_rollout_ring(Params P, uint4 *
 #endif
         for (int s = 0; s < k_steps; ++s) {
             if (live) { // padding lanes only keep the barrier count
-                const int a = policy_action<KIND>(e, cur_mask, tb, flags, policy_seed, (uint64_t)(P.index_offset + i),
-                                                  policy_t0 + (uint64_t)s);
+                const int a = policy_action<KIND>(e, cur_mask, tb, flags, pkey, policy_t0 + (uint64_t)s);
                 MSE_TL(e.tl, 0);
                 Snap sn;
                 env_dynamics<KIND, NOISE, false>(e, rng, P, tb, a, sm, flags, bales, sn);
@@ -776,9 +808,6 @@ __global__ __launch_bounds__(kRingThreads) void k_rollout_ring(Params P, uint4 *
             sn.lps = (int)((pk >> 22) & 1u);
             sn.done = (int)((pk >> 23) & 1u);
             sn.overflowed = (int)((pk >> 24) & 1u);
-#ifdef MSE_ABL_RING_NOO
-            if (sn.ce == 0x7fffffff)
-#endif
             if (live) { // the snapshot slots of padding lanes are never written
                 int k[4];
                 StepResult r = env_observe<KIND, NOISE>(sn, P, tb, k, o);
@@ -794,9 +823,6 @@ __global__ __launch_bounds__(kRingThreads) void k_rollout_ring(Params P, uint4 *
             }
             MSE_TL(tl, 1);
             const long long srow = (long long)s * P.n + row0;
-#ifdef MSE_ABL_RING_NOO
-            if (sn.ce == 0x7fffffff)
-#endif
             {
             // the mask tile reuses the obs tile: each wave finishes streaming its obs rows before it writes mask rows
             stage_and_store<KIND>(lds + L::stage_offset, -1, o, mbits, obs_out ? obs_out + srow * D : nullptr, nullptr, n_valid_block,
@@ -842,6 +868,10 @@ __global__ __launch_bounds__(kBlock) void k_reset(Params P, uint4 *__restrict__ 
             e.rng = pcg_seed(seed + 99);
             e.episode = 1u; // episodes are counted from the last seeded reset
             reseeded = true;
+            const Pcg srt = pcg_seed(seed + 2); // rng_sorting (env_super.py:171)
+            planes[(long long)PL_SORTRNG_STATE * P.n_pad + i] = pack_u64x2(srt.s_lo, srt.s_hi);
+            planes[(long long)PL_SORTRNG_INC * P.n_pad + i] = pack_u64x2(srt.i_lo, srt.i_hi);
+            planes[(long long)PL_SORTRNG_AUX * P.n_pad + i] = make_uint4(0, 0, 0, 0);
         } else {
             e.gen2 = unseeded_gen2(e);
             e.episode += 1u;
@@ -900,6 +930,23 @@ __global__ __launch_bounds__(kBlock) void k_sort_agent_obs(Params P, const uint4
     for (int j = 0; j < 13; ++j) obs_out[i * 13 + j] = o[j];
 }
 
+// The same preview for a pressing agent (env_monolith.py:198-210: get_press_obs() after the flow update)
+__global__ __launch_bounds__(kBlock) void k_press_agent_obs(Params P, const uint4 *__restrict__ planes,
+                                                            const uint32_t *__restrict__ table_image,
+                                                            float *__restrict__ obs_out)
+{
+    const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= P.n) return;
+    const Tables tb = tables_at(table_image, P);
+    Env e;
+    load_env<2, false>(e, planes, P, i);
+    update_environment(e);
+    float o[16];
+    press_obs(e, P, tb, o);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) obs_out[i * 16 + j] = o[j];
+}
+
 template <int KIND>
 __global__ __launch_bounds__(kBlock) void k_sample(Params P, const uint4 *__restrict__ planes,
                                                    const uint32_t *__restrict__ table_image, uint32_t flags,
@@ -910,8 +957,87 @@ __global__ __launch_bounds__(kBlock) void k_sample(Params P, const uint4 *__rest
     const Tables tb = tables_at(table_image, P);
     Env e;
     load_env<KIND, false>(e, planes, P, i);
-    action_out[i] = policy_action<KIND>(e, action_mask_bits<KIND>(e, P), tb, flags, policy_seed,
-                                        (uint64_t)(P.index_offset + i), policy_t);
+    action_out[i] = policy_action<KIND>(e, action_mask_bits<KIND>(e, P), tb, flags,
+                                        mse_policy_key(policy_seed, (uint64_t)(P.index_offset + i)), policy_t);
+}
+
+// numpy's Generator.choice(n) / choice(arr) without p: arr[bounded Lemire on the generator's buffered uint32]
+// (numpy _generator.pyx choice -> random_bounded_uint64 -> buffered_bounded_lemire_uint32); no draw when n == 1
+struct Rng32 {
+    Pcg g;
+    uint32_t uinteger;
+    int has;
+    __device__ __forceinline__ uint32_t next32()
+    {
+        if (has) {
+            has = 0;
+            return uinteger;
+        }
+        const uint64_t r = pcg_next64(g);
+        has = 1;
+        uinteger = (uint32_t)(r >> 32);
+        return (uint32_t)r;
+    }
+    __device__ __forceinline__ uint32_t lemire(uint32_t n) // uniform in [0, n), n >= 1
+    {
+        if (n <= 1u) return 0u;
+        uint64_t m = (uint64_t)next32() * n;
+        uint32_t leftover = (uint32_t)m;
+        if (leftover < n) {
+            const uint32_t threshold = (0xFFFFFFFFu - (n - 1u)) % n;
+            while (leftover < threshold) {
+                m = (uint64_t)next32() * n;
+                leftover = (uint32_t)m;
+            }
+        }
+        return (uint32_t)(m >> 32);
+    }
+};
+
+// Env_3_Monolith.step(mode='model') with no agents assigned (env_monolith.py:186-221): the sorting decision is
+// rng_sorting.choice([0, 1]), the press action rng_pressing.choice(flatnonzero(press_action_masks())) with masking
+// and rng_pressing.choice(11) without.  Both streams advance; the action is then stepped with masked semantics
+// (the reference applies it through press_action_rules without sanitising, env_monolith.py:254-257).
+__global__ __launch_bounds__(kBlock) void k_model_actions(Params P, uint4 *__restrict__ planes, uint32_t flags,
+                                                          int *__restrict__ action_out)
+{
+    const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= P.n) return;
+    Env e;
+    load_env<1, false>(e, planes, P, i); // KIND 1: with the rng_pressing planes
+    Rng32 srt, prs;
+    {
+        const uint4 a = planes[(long long)PL_SORTRNG_STATE * P.n_pad + i], b = planes[(long long)PL_SORTRNG_INC * P.n_pad + i];
+        const uint4 x = planes[(long long)PL_SORTRNG_AUX * P.n_pad + i];
+        srt.g.s_lo = (uint64_t)a.x | ((uint64_t)a.y << 32);
+        srt.g.s_hi = (uint64_t)a.z | ((uint64_t)a.w << 32);
+        srt.g.i_lo = (uint64_t)b.x | ((uint64_t)b.y << 32);
+        srt.g.i_hi = (uint64_t)b.z | ((uint64_t)b.w << 32);
+        srt.uinteger = x.x;
+        srt.has = (int)x.y;
+    }
+    prs.g = e.press;
+    prs.uinteger = e.press_uint;
+    prs.has = e.press_has;
+    const int sort_mode = (flags & MSE_MODEL_NO_SORT_DRAW) ? 0 : (int)srt.lemire(2u);
+    int press_action;
+    if (flags & MSE_MODEL_NO_PRESS_DRAW) {
+        press_action = 0;
+    } else if (flags & MSE_STEP_UNMASKED) {
+        press_action = (int)prs.lemire(11u);
+    } else {
+        const uint32_t bits = press_mask_bits(e, P);
+        press_action = select_kth_bit(bits, (int)prs.lemire((uint32_t)__popc(bits)));
+    }
+    action_out[i] = P.env_kind == 1 ? sort_mode : (P.env_kind == 2 ? press_action : sort_mode * 11 + press_action);
+    planes[(long long)PL_SORTRNG_STATE * P.n_pad + i] = pack_u64x2(srt.g.s_lo, srt.g.s_hi);
+    planes[(long long)PL_SORTRNG_AUX * P.n_pad + i] = make_uint4(srt.uinteger, (uint32_t)srt.has, 0, 0);
+    planes[(long long)PL_PRESS_STATE * P.n_pad + i] = pack_u64x2(prs.g.s_lo, prs.g.s_hi);
+    // rng_pressing's 32-bit buffer lives in PL_MISC2 {.w = uinteger, flag bit in .x}
+    uint4 m2 = planes[(long long)PL_MISC2 * P.n_pad + i];
+    m2.w = prs.uinteger;
+    m2.x = (m2.x & ~(FL_PRESS_HAS_U32 << 24)) | ((prs.has ? FL_PRESS_HAS_U32 : 0u) << 24);
+    planes[(long long)PL_MISC2 * P.n_pad + i] = m2;
 }
 
 // snapshot record <-> planes (column map: include/mse.h MSE_SNAP_*, shared with oracle/oracle.py SNAP)
@@ -964,12 +1090,20 @@ __global__ __launch_bounds__(kBlock) void k_get_state(Params P, const uint4 *__r
     if (Dd != nullptr)
         for (int m = 0; m < 4; ++m) Dd[i * 4 + m] = e.acc[m];
     if (R != nullptr) {
-        unsigned long long *w = R + i * 18;
+        unsigned long long *w = R + i * MSE_SNAP_RNG_WORDS;
         w[0] = e.rng.s_hi; w[1] = e.rng.s_lo; w[2] = e.rng.i_hi; w[3] = e.rng.i_lo; w[4] = 0; w[5] = 0;
         w[6] = e.noise.s_hi; w[7] = e.noise.s_lo; w[8] = e.noise.i_hi; w[9] = e.noise.i_lo; w[10] = 0; w[11] = 0;
         w[12] = e.press.s_hi; w[13] = e.press.s_lo; w[14] = e.press.i_hi; w[15] = e.press.i_lo;
         w[16] = (unsigned long long)e.press_has;
         w[17] = e.press_uint;
+        const uint4 ss = planes[(long long)PL_SORTRNG_STATE * P.n_pad + i], si = planes[(long long)PL_SORTRNG_INC * P.n_pad + i];
+        const uint4 sa = planes[(long long)PL_SORTRNG_AUX * P.n_pad + i];
+        w[18] = (uint64_t)ss.z | ((uint64_t)ss.w << 32);
+        w[19] = (uint64_t)ss.x | ((uint64_t)ss.y << 32);
+        w[20] = (uint64_t)si.z | ((uint64_t)si.w << 32);
+        w[21] = (uint64_t)si.x | ((uint64_t)si.y << 32);
+        w[22] = sa.y;
+        w[23] = sa.x;
     }
 }
 
@@ -1018,10 +1152,19 @@ __global__ __launch_bounds__(kBlock) void k_set_state(Params P, uint4 *__restric
                 make_uint4((uint32_t)r[36 + m], (uint32_t)r[41 + m], (uint32_t)r[46 + m], (uint32_t)r[51 + m]);
         e.episode = (uint32_t)r[60];
     }
-    if (Dd != nullptr)
-        for (int m = 0; m < 4; ++m) e.acc[m] = Dd[i * 4 + m];
+    if (Dd != nullptr) {
+        for (int m = 0; m < 4; ++m) {
+            e.acc[m] = Dd[i * 4 + m];
+            // no reachable state has an accuracy outside [clip(baseline [+ boost] - noise), 1]; the three-role rollout
+            // kernel's flow control (Params::ring_worst draws per step at most) is sized for that range
+            if (!(e.acc[m] >= P.acc_floor[m] && e.acc[m] <= 1.0)) atomicAdd(err_count, 1ull);
+        }
+    }
     if (R != nullptr) {
-        const unsigned long long *w = R + i * 18;
+        const unsigned long long *w = R + i * MSE_SNAP_RNG_WORDS;
+        planes[(long long)PL_SORTRNG_STATE * P.n_pad + i] = pack_u64x2(w[19], w[18]);
+        planes[(long long)PL_SORTRNG_INC * P.n_pad + i] = pack_u64x2(w[21], w[20]);
+        planes[(long long)PL_SORTRNG_AUX * P.n_pad + i] = make_uint4((uint32_t)w[23], (uint32_t)w[22], 0, 0);
         e.rng.s_hi = w[0]; e.rng.s_lo = w[1]; e.rng.i_hi = w[2]; e.rng.i_lo = w[3];
         e.noise.s_hi = w[6]; e.noise.s_lo = w[7]; e.noise.i_hi = w[8]; e.noise.i_lo = w[9];
         e.press.s_hi = w[12]; e.press.s_lo = w[13]; e.press.i_hi = w[14]; e.press.i_lo = w[15];
@@ -1047,6 +1190,9 @@ struct mse_env {
     bool pipelined;              // mse_rollout uses the dynamics/observer kernel (k_rollout_po)
     bool ring;                   // ... with RNG waves feeding an LDS ring (k_rollout_ring)
     uint64_t policy_t;
+    // opt-in trace of one env (mse_trace_begin): records_dev f64[capacity][MSE_TRACE_COLS], caller-owned
+    double *trace_rec;
+    int64_t trace_env, trace_capacity, trace_count;
 };
 
 static thread_local std::string g_last_error;
@@ -1264,9 +1410,23 @@ static void launch_step(mse_env *h, hipStream_t s, const int32_t *action, const 
 {
     const bool lit = h->literal;
     const size_t lds = lds_bytes_step<KIND>(h);
+    if (h->trace_rec != nullptr) { // the traced variant: one more record for env trace_env
+        double *rec = h->trace_rec + h->trace_count * MSE_TRACE_COLS;
+#define MSE_LAUNCH_STEP_T(NOISE, LIT)                                                                    \
+    hipLaunchKernelGGL((k_step<KIND, NOISE, LIT, true>), grid_of(h), dim3(kBlock), lds, s, h->P, h->planes, h->tables, \
+                       action, sort_mode, flags, obs, rew, rew64, done, mask, tobs, h->err_count, rec, (long long)h->trace_env)
+        if (h->noise_on) {
+            if (lit) MSE_LAUNCH_STEP_T(true, true); else MSE_LAUNCH_STEP_T(true, false);
+        } else {
+            if (lit) MSE_LAUNCH_STEP_T(false, true); else MSE_LAUNCH_STEP_T(false, false);
+        }
+#undef MSE_LAUNCH_STEP_T
+        h->trace_count += 1;
+        return;
+    }
 #define MSE_LAUNCH_STEP(NOISE, LIT)                                                                      \
     hipLaunchKernelGGL((k_step<KIND, NOISE, LIT>), grid_of(h), dim3(kBlock), lds, s, h->P, h->planes, h->tables, \
-                       action, sort_mode, flags, obs, rew, rew64, done, mask, tobs, h->err_count)
+                       action, sort_mode, flags, obs, rew, rew64, done, mask, tobs, h->err_count, (double *)nullptr, -1LL)
     if (h->noise_on) {
         if (lit) MSE_LAUNCH_STEP(true, true); else MSE_LAUNCH_STEP(true, false);
     } else {
@@ -1428,12 +1588,15 @@ int mse_create_indexed(mse_env **out, const mse_config *cfg, int64_t n_envs, int
     if (device_id < 0 || device_id >= n_dev) return fail(MSE_ERR_NO_DEVICE, "device_id out of range");
     MSE_HIP(hipSetDevice(device_id));
 
-    mse_env *h = new (std::nothrow) mse_env();
+    mse_env *h = new (std::nothrow) mse_env(); // value-initialised: device pointers start out null
     if (!h) return fail(MSE_ERR_INVALID_ARGUMENT, "out of host memory");
     h->cfg = *cfg;
     h->device = device_id;
     h->seeded = false;
     h->policy_t = 0;
+    h->trace_rec = nullptr;
+    h->trace_env = -1;
+    h->trace_capacity = h->trace_count = 0;
     h->noise_on = cfg->noise != 0.0;
     Params &P = h->P;
     std::memset(&P, 0, sizeof(P));
@@ -1488,6 +1651,11 @@ int mse_create_indexed(mse_env **out, const mse_config *cfg, int64_t n_envs, int
         // (>= clip(baseline [+ boost] - noise)); modes other than 0 / 1 (no boost) exist only for Env_2's
         // externally supplied sorting decision
         int worst = 0;
+        for (int m = 0; m < 4; ++m) {
+            const double lo = cfg->baseline_accuracy[m] - cfg->noise, hi = cfg->baseline_accuracy[m] + cfg->boost - cfg->noise;
+            const double lo_c = lo < 0.0 ? 0.0 : (lo > 1.0 ? 1.0 : lo), hi_c = hi < 0.0 ? 0.0 : (hi > 1.0 ? 1.0 : hi);
+            P.acc_floor[m] = lo_c < hi_c ? lo_c : hi_c;
+        }
         const int n_modes = cfg->env_kind == MSE_ENV_PRESS ? 3 : 2;
         for (int k = 1; k <= 2; ++k) {
             for (int mode = 0; mode < n_modes; ++mode) {
@@ -1512,9 +1680,7 @@ int mse_create_indexed(mse_env **out, const mse_config *cfg, int64_t n_envs, int
         const bool fits = worst <= kRingMaxPerStep && !h->literal && ring_lds <= (size_t)160 * 1024;
         h->ring = h->pipelined && fits && cfg->rollout_pipeline != 1;
         if (cfg->rollout_pipeline == 3 && !fits) {
-            (void)hipFree(h->planes);
-            (void)hipFree(h->err_count);
-            delete h;
+            delete h; // nothing is allocated on the device yet
             return fail(MSE_ERR_UNSUPPORTED_CONFIG, "rollout_pipeline=3 (ring kernel) needs at most 31 draws per step, "
                                                     "the integer draw path and an LDS image within 160 KiB");
         }
@@ -1539,9 +1705,13 @@ int mse_create_indexed(mse_env **out, const mse_config *cfg, int64_t n_envs, int
         delete h;
         return fail(MSE_ERR_HIP, std::string("hipMalloc(tables): ") + hipGetErrorString(e3));
     }
-    MSE_HIP(hipMemcpy(h->tables, image.data(), image.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-    MSE_HIP(hipMemset(h->planes, 0, bytes));
-    MSE_HIP(hipMemset(h->err_count, 0, sizeof(unsigned long long)));
+    hipError_t e4 = hipMemcpy(h->tables, image.data(), image.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+    if (e4 == hipSuccess) e4 = hipMemset(h->planes, 0, bytes);
+    if (e4 == hipSuccess) e4 = hipMemset(h->err_count, 0, sizeof(unsigned long long));
+    if (e4 != hipSuccess) {
+        (void)mse_destroy(h);
+        return fail(MSE_ERR_HIP, std::string("initialising the state planes / tables: ") + hipGetErrorString(e4));
+    }
     *out = h;
     return MSE_OK;
 }
@@ -1606,9 +1776,14 @@ int mse_step(mse_env *h, const int32_t *action, const int32_t *sort_mode, uint32
     if (!h) return fail(MSE_ERR_INVALID_ARGUMENT, "env is NULL");
     if (!h->seeded) return fail(MSE_ERR_NOT_RESET, "mse_step before mse_reset(seeds)");
     if (!action) return fail(MSE_ERR_INVALID_ARGUMENT, "action_dev is NULL");
-    if (flags & ~(MSE_STEP_UNMASKED | MSE_STEP_CHECK_OVERFLOW)) return fail(MSE_ERR_INVALID_ARGUMENT, "unknown step flag");
+    if (flags & ~(MSE_STEP_UNMASKED | MSE_STEP_CHECK_OVERFLOW | MSE_STEP_SANITIZE_LATE))
+        return fail(MSE_ERR_INVALID_ARGUMENT, "unknown step flag");
+    if ((flags & MSE_STEP_SANITIZE_LATE) && (h->P.env_kind != MSE_ENV_MONO || !(flags & MSE_STEP_UNMASKED)))
+        return fail(MSE_ERR_INVALID_ARGUMENT, "MSE_STEP_SANITIZE_LATE applies to Env_3 with MSE_STEP_UNMASKED only");
     if ((obs_out && !aligned16(obs_out)) || (mask_out && !aligned16(mask_out)))
         return fail(MSE_ERR_ALIGNMENT, "obs_out / mask_out must be 16-byte aligned");
+    if (h->trace_rec != nullptr && h->trace_count >= h->trace_capacity)
+        return fail(MSE_ERR_INVALID_ARGUMENT, "the trace buffer is full: mse_trace_end, or begin a trace with more capacity");
     hipStream_t s = static_cast<hipStream_t>(stream);
     switch (h->P.env_kind) {
     case 1: launch_step<1>(h, s, action, sort_mode, flags, obs_out, reward_out, reward64_out, done_out, mask_out, terminal_obs_out); break;
@@ -1629,8 +1804,12 @@ int mse_rollout(mse_env *h, int32_t k_steps, uint64_t policy_seed, const int32_t
     if (!h->seeded) return fail(MSE_ERR_NOT_RESET, "mse_rollout before mse_reset(seeds)");
     if (k_steps < 1) return fail(MSE_ERR_INVALID_ARGUMENT, "k_steps must be >= 1");
     if (!h->P.auto_reset) return fail(MSE_ERR_INVALID_ARGUMENT, "mse_rollout needs auto_reset=1");
-    if (flags & ~(MSE_STEP_UNMASKED | MSE_STEP_CHECK_OVERFLOW | MSE_ROLLOUT_RULE_BASED))
+    if (h->trace_rec != nullptr)
+        return fail(MSE_ERR_INVALID_ARGUMENT, "a trace is attached (mse_trace_begin): only mse_step records, end it first");
+    if (flags & ~(MSE_STEP_UNMASKED | MSE_STEP_CHECK_OVERFLOW | MSE_ROLLOUT_RULE_BASED | MSE_STEP_SANITIZE_LATE))
         return fail(MSE_ERR_INVALID_ARGUMENT, "unknown rollout flag");
+    if ((flags & MSE_STEP_SANITIZE_LATE) && (h->P.env_kind != MSE_ENV_MONO || !(flags & MSE_STEP_UNMASKED)))
+        return fail(MSE_ERR_INVALID_ARGUMENT, "MSE_STEP_SANITIZE_LATE applies to Env_3 with MSE_STEP_UNMASKED only");
     hipStream_t s = static_cast<hipStream_t>(stream);
     switch (h->P.env_kind) {
     case 1: launch_rollout<1>(h, s, k_steps, policy_seed, sort_mode, flags, actions_out, obs_out, reward_out, done_out, mask_out); break;
@@ -1666,6 +1845,42 @@ int mse_rule_actions(mse_env *h, int32_t *action_out, void *stream)
     return sample_actions_impl(h, MSE_ROLLOUT_RULE_BASED, 0, action_out, stream);
 }
 
+int mse_model_actions(mse_env *h, uint32_t flags, int32_t *action_out, void *stream)
+{
+    if (!h || !action_out) return fail(MSE_ERR_INVALID_ARGUMENT, "env/action_out is NULL");
+    if (!h->seeded) return fail(MSE_ERR_NOT_RESET, "mse_model_actions before mse_reset(seeds)");
+    if (flags & ~(MSE_STEP_UNMASKED | MSE_MODEL_NO_SORT_DRAW | MSE_MODEL_NO_PRESS_DRAW))
+        return fail(MSE_ERR_INVALID_ARGUMENT, "unknown flag");
+    if (h->P.env_kind != MSE_ENV_MONO)
+        return fail(MSE_ERR_INVALID_ARGUMENT, "mode='model' exists on Env_3_Monolith only (env_monolith.py:186)");
+    hipLaunchKernelGGL(k_model_actions, grid_of(h), dim3(kBlock), 0, static_cast<hipStream_t>(stream), h->P, h->planes,
+                       flags, action_out);
+    MSE_CHECK_LAUNCH();
+    return MSE_OK;
+}
+
+int mse_trace_begin(mse_env *h, int64_t env_index, double *records_dev, int64_t capacity)
+{
+    if (!h || !records_dev) return fail(MSE_ERR_INVALID_ARGUMENT, "env/records_dev is NULL");
+    if (env_index < 0 || env_index >= h->P.n) return fail(MSE_ERR_INVALID_ARGUMENT, "env_index out of range");
+    if (capacity < 1) return fail(MSE_ERR_INVALID_ARGUMENT, "capacity must be >= 1");
+    h->trace_rec = records_dev;
+    h->trace_env = env_index;
+    h->trace_capacity = capacity;
+    h->trace_count = 0;
+    return MSE_OK;
+}
+
+int mse_trace_end(mse_env *h, int64_t *n_records_out)
+{
+    if (!h) return fail(MSE_ERR_INVALID_ARGUMENT, "env is NULL");
+    if (n_records_out) *n_records_out = h->trace_rec ? h->trace_count : 0;
+    h->trace_rec = nullptr;
+    h->trace_env = -1;
+    h->trace_capacity = h->trace_count = 0;
+    return MSE_OK;
+}
+
 int mse_action_masks(mse_env *h, uint8_t *mask_out, void *stream)
 {
     if (!h || !mask_out) return fail(MSE_ERR_INVALID_ARGUMENT, "env/mask_out is NULL");
@@ -1688,6 +1903,15 @@ int mse_sort_agent_obs(mse_env *h, float *obs13_out, void *stream)
     return MSE_OK;
 }
 
+int mse_press_agent_obs(mse_env *h, float *obs16_out, void *stream)
+{
+    if (!h || !obs16_out) return fail(MSE_ERR_INVALID_ARGUMENT, "env/obs16_out is NULL");
+    hipLaunchKernelGGL(k_press_agent_obs, grid_of(h), dim3(kBlock), 0, static_cast<hipStream_t>(stream), h->P, h->planes,
+                       h->tables, obs16_out);
+    MSE_CHECK_LAUNCH();
+    return MSE_OK;
+}
+
 int mse_get_state(mse_env *h, int64_t *ints_out, double *dbls_out, uint64_t *rng_out, void *stream)
 {
     if (!h) return fail(MSE_ERR_INVALID_ARGUMENT, "env is NULL");
@@ -1705,6 +1929,20 @@ int mse_set_state(mse_env *h, const int64_t *ints_in, const double *dbls_in, con
                        reinterpret_cast<const unsigned long long *>(rng_in), h->err_count);
     MSE_CHECK_LAUNCH();
     if (rng_in) h->seeded = true;
+    return MSE_OK;
+}
+
+int mse_get_policy_step(const mse_env *h, uint64_t *t_out)
+{
+    if (!h || !t_out) return fail(MSE_ERR_INVALID_ARGUMENT, "env/t_out is NULL");
+    *t_out = h->policy_t;
+    return MSE_OK;
+}
+
+int mse_set_policy_step(mse_env *h, uint64_t t)
+{
+    if (!h) return fail(MSE_ERR_INVALID_ARGUMENT, "env is NULL");
+    h->policy_t = t;
     return MSE_OK;
 }
 

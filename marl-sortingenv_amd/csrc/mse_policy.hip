@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "mse.h"
+#include "mse_policy_stream.h"
 
 int mse_internal_fail(int status, const char *msg); // mse_lib.hip: sets mse_last_error()
 
@@ -42,19 +43,6 @@ __device__ __forceinline__ float fast_tanh(float x)
 
 __device__ __forceinline__ float xhalf(float v) { return __shfl_xor(v, 32); } // the other half's value for this env
 __device__ __forceinline__ int xhalf_i(int v) { return __shfl_xor(v, 32); }
-
-// the counter-based stream of the random policy (mse_device.h policy_u32), one word per (env, step)
-__device__ __forceinline__ uint32_t policy_word(uint64_t seed, uint64_t env_index, uint64_t t)
-{
-    uint32_t x = (uint32_t)seed + (uint32_t)env_index * 0x9E3779B1u + (uint32_t)t * 0x85EBCA77u;
-    x ^= (uint32_t)(seed >> 32) * 0x27D4EB2Fu;
-    x ^= x >> 16;
-    x *= 0x85EBCA6Bu;
-    x ^= x >> 13;
-    x *= 0xC2B2AE35u;
-    x ^= x >> 16;
-    return x;
-}
 
 struct PolicyArgs {
     long long n;
@@ -200,7 +188,7 @@ __global__ __launch_bounds__(512) void k_policy_mlp(PolicyArgs P, const float *_
             const bool take = ob > best || (ob == best && oa < act);
             act = take ? oa : act;
         } else {
-            const uint32_t word = policy_word(P.seed, (uint64_t)(P.index_offset + env), P.t);
+            const uint32_t word = mse_policy_word(mse_policy_key(P.seed, (uint64_t)(P.index_offset + env)), P.t);
             const float target = (float)(word >> 8) * 5.9604644775390625e-8f * total; // u in [0, 1) times the mass
             float cum = 0.0f; // inclusive cumulative mass in action order, walked group by group
             int last = -1;    // the last action of this lane with any mass (fallback when target rounds up to the total)

@@ -229,7 +229,7 @@ def main():
     print(f"total {total/1024:.1f} KiB")
 
 
-if __name__ == "__main__" and "--rule-based" not in sys.argv:
+if __name__ == "__main__" and not any(a in sys.argv for a in ("--rule-based", "--model", "--trace", "--random-mode")):
     main()
 
 
@@ -259,3 +259,139 @@ def gen_rule_based(seeds=range(1, 11), steps=200):
 
 if __name__ == "__main__" and "--rule-based" in sys.argv:
     gen_rule_based()
+
+
+def _pack(rows, meta):
+    out = {k: np.asarray(v) for k, v in rows.items()}
+    out["op"] = out["op"].astype(np.uint8)
+    out["arg"] = out["arg"].astype(np.uint64)
+    out["sort_mode"] = out["sort_mode"].astype(np.int8)
+    out["flags"] = out["flags"].astype(np.uint8)
+    out["terminated"] = out["terminated"].astype(np.uint8)
+    out["rng"] = out["rng"].astype(np.uint64)
+    out["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    return out
+
+
+def gen_model_fallback():
+    """Env_3_Monolith.step(action=None, mode='model') with NO agents assigned (env_monolith.py:186-221): the env
+    draws rng_sorting.choice([0, 1]) and rng_pressing.choice(valid) / choice(11) itself.  Same row format as the
+    step traces; `arg` of a step row is the action the reference reported in info["action"]; `rng` holds all four
+    streams (rng, rng_noise, rng_pressing, rng_sorting)."""
+    cls = ref_harness.load()["mono"]
+    for name, masking, noise, seeds, seg in (("model_mono_n0_masked_s2_s17", True, 0.0, [2, 17], 210),
+                                             ("model_mono_n5_unmasked_s4_s23", False, 0.05, [4, 23], 210)):
+        env = cls(max_steps=200, seed=seeds[0], noise_sorting=noise, balesize=200)
+        rows = {k: [] for k in ("op", "arg", "sort_mode", "flags", "obs", "reward", "terminated", "mask", "ints", "dbls", "rng")}
+
+        def record(op, arg, obs, rew, term):
+            I, Dd, R = ref_harness.snapshot(env)
+            for k, v in (("op", op), ("arg", arg), ("sort_mode", -1), ("flags", 0), ("obs", np.asarray(obs, dtype=np.float32)),
+                         ("reward", float(rew)), ("terminated", int(term)), ("mask", np.asarray(env.action_masks(), dtype=np.uint8)),
+                         ("ints", I), ("dbls", Dd), ("rng", R)):
+                rows[k].append(v)
+
+        for seed in seeds:
+            obs, _ = env.reset(seed=seed)
+            record(1, seed, obs, 0.0, 0)
+            for _ in range(seg):
+                obs, rew, term, trunc, info = env.step(action=None, mode="model", use_action_masking=masking)
+                record(0, int(info["action"]), obs, rew, term)
+        meta = dict(name=name, kind="mono", max_steps=200, noise_sorting=noise, balesize=200, ctor_seed=int(seeds[0]),
+                    policy="mode='model' without agents", masking=bool(masking), check_overflow=False,
+                    numpy=np.__version__, config_overrides={}, generator="oracle/gen_golden.py --model from the imported reference")
+        out = _pack(rows, meta)
+        path = os.path.join(OUT_DIR, name + ".npz")
+        np.savez_compressed(path, **out)
+        print(f"{name:48s} rows={len(out['op']):4d}  {os.path.getsize(path)/1024:7.1f} KiB")
+
+
+def gen_trace():
+    """One episode per fixture with the reference's per-env ledgers captured at its end: reward_data,
+    press_actions_per_timestep and the full bale_count lists (what utils/plotting.py:32-48 reads)."""
+    classes = ref_harness.load()
+    for name, kind, kw, seed, policy, masking, check_overflow, steps in (
+            ("trace_mono_n5_unmasked_s3", "mono", dict(max_steps=150, noise_sorting=0.05, balesize=200), 3, "ignore_mask_uniform", False, False, 150),
+            ("trace_mono_n0_greedy_s5_bale150", "mono", dict(max_steps=120, noise_sorting=0.0, balesize=150), 5, "greedy_press", True, False, 120),
+            ("trace_mono_n0_ignoremask_s8", "mono", dict(max_steps=150, noise_sorting=0.0, balesize=200), 8, "ignore_mask_uniform", True, False, 150),
+            ("trace_press_n0_unmasked_s4", "press", dict(max_steps=150, noise_sorting=0.0, balesize=200), 4, "ignore_mask_uniform", False, False, 150),
+            ("trace_sort_n5_masked_s6", "sort", dict(max_steps=150, noise_sorting=0.05, balesize=200), 6, "masked_uniform", True, False, 150),
+            ("trace_mono_n5_overflow_s1", "mono", dict(max_steps=200, noise_sorting=0.05, balesize=200), 1, "noop", True, True, 200)):
+        env = classes[kind](seed=seed, **kw)
+        agent = None
+        if kind == "press":
+            agent = ref_harness.ScriptedSortAgent()
+            env.set_agents(sort_agent=agent)
+        prng = np.random.default_rng(sum(name.encode()) * 104729)
+        rows = {k: [] for k in ("op", "arg", "sort_mode", "flags", "obs", "reward", "terminated", "mask", "ints", "dbls", "rng")}
+
+        def record(op, arg, sm, flags, obs, rew, term):
+            I, Dd, R = ref_harness.snapshot(env)
+            for k, v in (("op", op), ("arg", arg), ("sort_mode", sm), ("flags", flags), ("obs", np.asarray(obs, dtype=np.float32)),
+                         ("reward", float(rew)), ("terminated", int(term)), ("mask", np.asarray(env.action_masks(), dtype=np.uint8)),
+                         ("ints", I), ("dbls", Dd), ("rng", R)):
+                rows[k].append(v)
+
+        flags = (0 if masking else STEP_UNMASKED) | (STEP_CHECK_OVERFLOW if check_overflow else 0)
+        obs, _ = env.reset(seed=seed)
+        record(1, seed, -1, 0, obs, 0.0, 0)
+        for t in range(steps):
+            a, sm = choose(policy, kind, env, prng, t)
+            if kind == "press":
+                agent.next_mode = sm
+            obs, rew, term, trunc, info = env.step(a, use_action_masking=masking, check_overflow=check_overflow)
+            record(0, a, sm if kind == "press" else -1, flags, obs, rew, term)
+            if term:
+                break
+        meta = dict(name=name, kind=kind, max_steps=kw["max_steps"], noise_sorting=kw["noise_sorting"], balesize=kw["balesize"],
+                    ctor_seed=int(seed), policy=policy, masking=bool(masking), check_overflow=bool(check_overflow),
+                    numpy=np.__version__, config_overrides={}, generator="oracle/gen_golden.py --trace from the imported reference")
+        out = _pack(rows, meta)
+        for k, v in ref_harness.ledgers(env).items():
+            out["ledger_" + k] = v
+        path = os.path.join(OUT_DIR, name + ".npz")
+        np.savez_compressed(path, **out)
+        print(f"{name:48s} rows={len(out['op']):4d} press_log={len(out['ledger_press_log'])} "
+              f"bales={sum(len(out['ledger_bales_' + m]) for m in 'ABCDE')}  {os.path.getsize(path)/1024:7.1f} KiB")
+
+
+def gen_random_mode():
+    """Env_3_Monolith.step(action=None, mode='random') (env_monolith.py:152-164, 245-253): actions drawn from the
+    process-global np.random that reset(seed) seeds (env_super.py:177); without masking the press action is sanitised
+    AFTER sort_material.  Same row format as the step traces; `arg` of a step row = info["action"]."""
+    cls = ref_harness.load()["mono"]
+    for name, masking, noise, seeds, seg in (("randmode_mono_n0_masked_s5_s31", True, 0.0, [5, 31], 205),
+                                             ("randmode_mono_n5_unmasked_s6_s12", False, 0.05, [6, 12], 205)):
+        env = cls(max_steps=200, seed=seeds[0], noise_sorting=noise, balesize=200)
+        rows = {k: [] for k in ("op", "arg", "sort_mode", "flags", "obs", "reward", "terminated", "mask", "ints", "dbls", "rng")}
+
+        def record(op, arg, obs, rew, term):
+            I, Dd, R = ref_harness.snapshot(env)
+            for k, v in (("op", op), ("arg", arg), ("sort_mode", -1), ("flags", 0), ("obs", np.asarray(obs, dtype=np.float32)),
+                         ("reward", float(rew)), ("terminated", int(term)), ("mask", np.asarray(env.action_masks(), dtype=np.uint8)),
+                         ("ints", I), ("dbls", Dd), ("rng", R)):
+                rows[k].append(v)
+
+        for seed in seeds:
+            obs, _ = env.reset(seed=seed)
+            record(1, seed, obs, 0.0, 0)
+            for _ in range(seg):
+                obs, rew, term, trunc, info = env.step(action=None, mode="random", use_action_masking=masking)
+                record(0, int(info["action"]), obs, rew, term)
+        meta = dict(name=name, kind="mono", max_steps=200, noise_sorting=noise, balesize=200, ctor_seed=int(seeds[0]),
+                    policy="mode='random' (global np.random)", masking=bool(masking), check_overflow=False,
+                    numpy=np.__version__, config_overrides={}, generator="oracle/gen_golden.py --random-mode from the imported reference")
+        out = _pack(rows, meta)
+        for k, v in ref_harness.ledgers(env).items():
+            out["ledger_" + k] = v
+        path = os.path.join(OUT_DIR, name + ".npz")
+        np.savez_compressed(path, **out)
+        print(f"{name:48s} rows={len(out['op']):4d}  {os.path.getsize(path)/1024:7.1f} KiB")
+
+
+if __name__ == "__main__" and "--random-mode" in sys.argv:
+    gen_random_mode()
+if __name__ == "__main__" and "--model" in sys.argv:
+    gen_model_fallback()
+if __name__ == "__main__" and "--trace" in sys.argv:
+    gen_trace()

@@ -593,10 +593,27 @@ static void sort_material(orc_env *e)
     }
 }
 
+static void log_entry(orc_env *e, int code, int mat)
+{
+    e->last_log_code = code;
+    e->last_log_mat = mat;
+    if (e->step_n_log < 2) {
+        e->step_log_code[e->step_n_log] = code;
+        e->step_log_mat[e->step_n_log] = mat;
+    }
+    e->step_n_log++;
+}
+
 /* env_super.py:661-687 press_bale */
 static void press_bale(orc_env *e, int mat, int64_t n, double q)
 {
     int32_t qi = (int32_t)(q * 100.0); /* int(q*100): truncation */
+    if (e->step_n_bale < 2) {
+        e->step_bale_mat[e->step_n_bale] = mat;
+        e->step_bale_n[e->step_n_bale] = n;
+        e->step_bale_q[e->step_n_bale] = qi;
+    }
+    e->step_n_bale++;
     int64_t S = e->cfg.bale_standard_size;
     int64_t full = n / S, rem = n % S;
     for (int64_t k = 0; k < full; ++k) bales_push(e, mat, S, qi);
@@ -632,12 +649,10 @@ static void use_press(orc_env *e, int press, int mat)
 {
     int p = press - 1;
     if (e->press_timer[p] > 0) { /* :725-733 busy */
-        e->last_log_code = press == 1 ? 111 : 222;
-        e->last_log_mat = mat;
+        log_entry(e, press == 1 ? 111 : 222, mat);
         return;
     }
-    e->last_log_code = press;
-    e->last_log_mat = mat;
+    log_entry(e, press, mat); /* :736 */
     int64_t total = level_of(e, mat);
     e->last_press_started = 1;
     e->last_press_amount = total;
@@ -660,8 +675,7 @@ static void press_action_rules(orc_env *e, int press_action)
 {
     check_press_status(e);
     if (press_action == 0) {
-        e->last_log_code = 0;
-        e->last_log_mat = -1;
+        log_entry(e, 0, -1);
         return;
     }
     /* env_super.py:804-809 press_discrete_to_action */
@@ -773,11 +787,18 @@ int orc_env_step(orc_env *e, int32_t action, int32_t sort_mode_in, uint32_t flag
 {
     const int kind = e->cfg.env_kind;
     const int unmasked = (flags & ORC_STEP_UNMASKED) != 0;
+    const int late = (flags & ORC_STEP_SANITIZE_LATE) != 0; /* Env_3 mode='random' without masking */
     if (action < 0 || action >= orc_env_num_actions(e)) return -2;
 
     e->last_log_code = -1;
     e->last_log_mat = -1;
     e->last_internal_press_action = 0;
+    e->step_n_log = e->step_n_bale = 0;
+    for (int q = 0; q < 2; ++q) {
+        e->step_log_code[q] = e->step_log_mat[q] = e->step_bale_mat[q] = e->step_bale_q[q] = -1;
+        e->step_bale_n[q] = -1;
+    }
+    e->step_action = action;
 
     /* input_action_rules: draws rng_input.integers(60, 81); the value is discarded downstream
      * (env_super.py:911-922, :433,445) */
@@ -793,9 +814,8 @@ int orc_env_step(orc_env *e, int32_t action, int32_t sort_mode_in, uint32_t flag
     } else {
         sort_mode = action / 11; /* env_monolith.py:127-129 */
         press_action = action % 11;
-        if (unmasked && !validate_press_action(e, press_action)) { /* env_monolith.py:132-138 */
-            e->last_log_code = press_action <= 5 ? 111 : 222;
-            e->last_log_mat = (press_action - 1) % 5;
+        if (unmasked && !late && !validate_press_action(e, press_action)) { /* env_monolith.py:132-138 */
+            log_entry(e, press_action <= 5 ? 111 : 222, (press_action - 1) % 5);
             run_press_rules = 0; /* press_action_tuple=None: no tick this step (:237-243) */
         }
     }
@@ -810,7 +830,14 @@ int orc_env_step(orc_env *e, int32_t action, int32_t sort_mode_in, uint32_t flag
         /* env_2_press.py:125-131: Env_2 validates against the POST-sort levels (Env_3 validates
          * at decode time, before the sort: env_monolith.py:132) and still ticks the timers:
          * press_action_rules((None,None)) :138 */
+        log_entry(e, press_action <= 5 ? 111 : 222, (press_action - 1) % 5);
         press_action = 0;
+    }
+    else if (kind == ORC_ENV_MONO && unmasked && late && !validate_press_action(e, press_action)) {
+        /* env_monolith.py:245-253: mode='random' without masking sanitises in the "apply" section, after
+         * sort_material; an invalid action is logged and press_action_rules is not called (no tick) */
+        log_entry(e, press_action <= 5 ? 111 : 222, (press_action - 1) % 5);
+        run_press_rules = 0;
     }
     /* Env_2 unmasked-invalid: the ledger gets the invalid entry first and the (0,None)
      * no-op entry after it, so the last entry reads as a no-op there. */
@@ -822,23 +849,33 @@ int orc_env_step(orc_env *e, int32_t action, int32_t sort_mode_in, uint32_t flag
         if (obs_out) orc_env_obs(e, obs_out);
         *reward_out = e->cfg.overflow_termination_penalty;
         *terminated_out = 1;
+        /* _log_step_data: env_monolith.py:271 (reward/2 each), env_1_sort.py:141 and env_2_press.py:152 (0, reward) */
+        e->step_reward = *reward_out;
+        e->step_r_sort = kind == ORC_ENV_MONO ? *reward_out / 2 : 0.0;
+        e->step_r_press = kind == ORC_ENV_MONO ? *reward_out / 2 : *reward_out;
+        e->step_done = 1;
         return 0;
     }
 
     double reward;
+    e->step_r_sort = e->step_r_press = 0.0; /* env_1_sort.py:151, env_2_press.py:162, env_monolith.py:282 */
     if (kind == ORC_ENV_SORT)
-        reward = sorting_reward(e);
+        reward = e->step_r_sort = sorting_reward(e);
     else if (kind == ORC_ENV_PRESS)
-        reward = press_reward(e);
+        reward = e->step_r_press = press_reward(e);
     else {
         double rs = sorting_reward(e);
         double rp = press_reward(e);
         reward = rs + rp; /* env_monolith.py:274-276 */
+        e->step_r_sort = rs;
+        e->step_r_press = rp;
     }
     if (obs_out) orc_env_obs(e, obs_out);
     e->current_step += 1;
     *terminated_out = e->current_step >= e->cfg.max_steps;
     *reward_out = reward;
+    e->step_reward = reward;
+    e->step_done = *terminated_out;
     return 0;
 }
 
@@ -898,25 +935,92 @@ void orc_env_snapshot(const orc_env *e, int64_t *I, double *D, uint64_t *R)
     pack_rng(&e->rng, R);
     pack_rng(&e->rng_noise, R + 6);
     pack_rng(&e->rng_pressing, R + 12);
+    pack_rng(&e->rng_sorting, R + 18);
+}
+
+/* ====================================================================================== *
+ *  mode='model' without agents, trace record, bale lists
+ * ====================================================================================== */
+
+/* env_monolith.py:186-221 with sort_agent = press_agent = None */
+int32_t orc_env_model_fallback_action(orc_env *e, int use_action_masking)
+{
+    /* :195 rng_sorting.choice([0, 1]): an index draw over two entries */
+    int sort_mode = (int)orc_pcg64_integers(&e->rng_sorting, 0, 2);
+    int press_action;
+    if (use_action_masking) { /* :213-217 rng_pressing.choice(flatnonzero(press_action_masks())) */
+        uint8_t m11[11];
+        int valid[11], n = 0;
+        press_mask(e, m11);
+        for (int a = 0; a < 11; ++a)
+            if (m11[a]) valid[n++] = a;
+        press_action = n > 0 ? valid[(int)orc_pcg64_integers(&e->rng_pressing, 0, n)] : 0;
+    } else { /* :219 rng_pressing.choice(11) */
+        press_action = (int)orc_pcg64_integers(&e->rng_pressing, 0, 11);
+    }
+    return sort_mode * 11 + press_action; /* :221 */
+}
+
+void orc_env_trace_record(const orc_env *e, double *t)
+{
+    for (int c = 0; c < 40; ++c) t[c] = 0.0;
+    t[0] = e->step_action;
+    t[1] = e->step_r_sort;
+    t[2] = e->step_r_press;
+    t[3] = e->sensor_mode;
+    for (int m = 0; m < 4; ++m) {
+        t[4 + m] = e->belt[m];
+        t[8 + m] = (double)e->cont_true[m];
+        t[12 + m] = (double)e->cont_false[m];
+    }
+    t[16] = (double)e->cont_e;
+    t[17] = e->step_n_log;
+    t[22] = e->step_n_bale;
+    for (int q = 0; q < 2; ++q) {
+        t[18 + 2 * q] = e->step_log_code[q];
+        t[19 + 2 * q] = e->step_log_mat[q];
+        t[23 + 3 * q] = e->step_bale_mat[q];
+        t[24 + 3 * q] = (double)e->step_bale_n[q];
+        t[25 + 3 * q] = e->step_bale_q[q];
+    }
+    t[29] = e->step_done;
+    t[30] = e->current_step;
+    t[31] = e->last_internal_press_action;
+    t[32] = e->step_reward;
+    for (int m = 0; m < 4; ++m) t[33 + m] = e->acc_belt[m];
+}
+
+int32_t orc_env_bales(const orc_env *e, int m, int64_t *sizes, int32_t *qs, int32_t cap)
+{
+    for (int k = 0; k < e->n_bales[m] && k < cap; ++k) {
+        sizes[k] = e->bales[m][k].size;
+        qs[k] = e->bales[m][k].q;
+    }
+    return e->n_bales[m];
 }
 
 /* ====================================================================================== *
  *  masked-uniform random rollout (bench.py cpu_baseline leg)
  * ====================================================================================== */
 
-/* policy word shared with the HIP rollout kernel: see DESIGN.md "random policy" */
-static uint32_t policy_u32(uint64_t seed, uint64_t env_index, uint64_t t)
+/* the workload's policy stream (same shape as the HIP rollout kernel's: key by (seed, env), murmur3 finaliser of
+ * (t * odd) ^ key); only the bench's cpu_baseline leg uses it, parity never depends on it */
+static uint32_t fmix32(uint32_t h)
 {
-    const uint32_t s32 = (uint32_t)seed ^ ((uint32_t)(seed >> 32) * 0x85EBCA6Bu);
-    const uint32_t g32 = (uint32_t)env_index ^ ((uint32_t)(env_index >> 32) * 0xC2B2AE35u);
-    const uint32_t t32 = (uint32_t)t ^ ((uint32_t)(t >> 32) * 0x27D4EB2Fu);
-    uint32_t h = s32 + g32 * 0x9E3779B1u + t32 * 0x85EBCA77u;
     h ^= h >> 16;
     h *= 0x85EBCA6Bu;
     h ^= h >> 13;
     h *= 0xC2B2AE35u;
     h ^= h >> 16;
     return h;
+}
+static uint32_t policy_u32(uint64_t seed, uint64_t env_index, uint64_t t)
+{
+    const uint32_t s = fmix32((uint32_t)seed ^ fmix32((uint32_t)(seed >> 32) + 0x9E3779B9u));
+    const uint32_t g = (uint32_t)env_index * 0x9E3779B1u + (uint32_t)(env_index >> 32) * 0xC2B2AE3Du;
+    const uint32_t key = fmix32(s + g);
+    const uint32_t c = (uint32_t)t * 0x85EBCA77u + (uint32_t)(t >> 32) * 0x27D4EB2Fu;
+    return fmix32(c ^ key);
 }
 
 double orc_env_random_rollout(orc_env *e, int64_t n_steps, uint64_t policy_seed)

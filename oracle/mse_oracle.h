@@ -55,7 +55,7 @@ int64_t  orc_rint_i64(double x);                 /* int(round(np.float64))      
 enum { ORC_ENV_SORT = 1, ORC_ENV_PRESS = 2, ORC_ENV_MONO = 3 };
 
 /* step flags */
-enum { ORC_STEP_UNMASKED = 1u, ORC_STEP_CHECK_OVERFLOW = 2u };
+enum { ORC_STEP_UNMASKED = 1u, ORC_STEP_CHECK_OVERFLOW = 2u, ORC_STEP_SANITIZE_LATE = 8u };
 
 typedef struct {
     /* simulation (config.yml:4-9) */
@@ -116,6 +116,15 @@ typedef struct {
     /* Env_1: press action sampled inside the env this step (0..10) */
     int32_t last_internal_press_action;
     int64_t draws_this_step;
+
+    /* everything the last step appended to the reference's per-env ledgers (the opt-in trace of the HIP engine
+     * records the same): press_actions_per_timestep entries in order, press_bale calls in order, the two
+     * arguments of _log_step_data */
+    int32_t step_n_log, step_log_code[2], step_log_mat[2];
+    int32_t step_n_bale, step_bale_mat[2], step_bale_q[2];
+    int64_t step_bale_n[2];
+    double  step_r_sort, step_r_press, step_reward;
+    int32_t step_action, step_done;
 } orc_env;
 
 void orc_config_default(orc_config *cfg);
@@ -140,7 +149,19 @@ int  orc_env_num_actions(const orc_env *e);
 /* snapshot: fixed layout shared with tests (see oracle/oracle.py SNAP_*) */
 #define ORC_SNAP_INTS 71
 #define ORC_SNAP_DBLS 8
-void orc_env_snapshot(const orc_env *e, int64_t *ints, double *dbls, uint64_t *rng_words /*[3*6]*/);
+#define ORC_SNAP_RNG_WORDS 24 /* rng, rng_noise, rng_pressing, rng_sorting x 6 words */
+void orc_env_snapshot(const orc_env *e, int64_t *ints, double *dbls, uint64_t *rng_words /*[4*6]*/);
+
+/* Env_3_Monolith.step(mode='model') with no agents assigned (env_monolith.py:186-221): draws the sorting decision
+ * from rng_sorting.choice([0, 1]) and the press action from rng_pressing.choice(valid) (masked) or
+ * rng_pressing.choice(11) (unmasked); returns mode * 11 + press action.  The caller steps it with masked
+ * semantics (env_monolith.py:254-257 applies it through press_action_rules without sanitising). */
+int32_t orc_env_model_fallback_action(orc_env *e, int use_action_masking);
+
+/* the last step as one trace record, column layout of include/mse.h MSE_TRACE_* (40 doubles) */
+void orc_env_trace_record(const orc_env *e, double *rec40);
+/* full bale_count list of material m (0..4): up to `cap` (size, q) pairs; returns the list's length */
+int32_t orc_env_bales(const orc_env *e, int m, int64_t *sizes, int32_t *qs, int32_t cap);
 
 /* run a masked-uniform random rollout of n_steps on one env with auto-reset (unseeded rule);
  * used by bench.py's cpu_baseline leg.  Returns sum of rewards (to defeat dead-code elimination). */

@@ -16,9 +16,9 @@ _SO = os.path.join(_HERE, "_build", "libmse_oracle.so")
 
 ENV_SORT, ENV_PRESS, ENV_MONO = 1, 2, 3
 KIND_BY_NAME = {"sort": ENV_SORT, "press": ENV_PRESS, "mono": ENV_MONO}
-STEP_UNMASKED, STEP_CHECK_OVERFLOW = 1, 2
+STEP_UNMASKED, STEP_CHECK_OVERFLOW, STEP_SANITIZE_LATE = 1, 2, 8
 
-SNAP_INTS, SNAP_DBLS = 71, 8
+SNAP_INTS, SNAP_DBLS, SNAP_RNG_WORDS = 71, 8, 24  # rng words: rng, rng_noise, rng_pressing, rng_sorting x 6
 # integer snapshot layout (orc_env_snapshot)
 SNAP = {
     "input": slice(0, 4), "belt": slice(4, 8), "sorting": slice(8, 12),
@@ -114,6 +114,11 @@ def lib() -> C.CDLL:
         L.orc_env_num_actions.argtypes = [C.c_void_p]
         L.orc_env_num_actions.restype = C.c_int
         L.orc_env_snapshot.argtypes = [C.c_void_p, P(i64), P(dbl), P(u64)]
+        L.orc_env_model_fallback_action.argtypes = [C.c_void_p, C.c_int]
+        L.orc_env_model_fallback_action.restype = i32
+        L.orc_env_trace_record.argtypes = [C.c_void_p, P(dbl)]
+        L.orc_env_bales.argtypes = [C.c_void_p, C.c_int, P(i64), P(i32), i32]
+        L.orc_env_bales.restype = i32
         L.orc_env_random_rollout.argtypes = [C.c_void_p, i64, u64]
         L.orc_env_random_rollout.restype = dbl
         _lib = L
@@ -162,11 +167,12 @@ class OracleEnv:
                              obs.ctypes.data_as(C.POINTER(C.c_float)))
         return obs
 
-    def step(self, action, sort_mode=-1, use_action_masking=True, check_overflow=False):
+    def step(self, action, sort_mode=-1, use_action_masking=True, check_overflow=False, sanitize_late=False):
         obs = np.zeros(self.obs_dim, dtype=np.float32)
         rew = C.c_double(0.0)
         term = C.c_int32(0)
-        flags = (0 if use_action_masking else STEP_UNMASKED) | (STEP_CHECK_OVERFLOW if check_overflow else 0)
+        flags = (0 if use_action_masking else STEP_UNMASKED) | (STEP_CHECK_OVERFLOW if check_overflow else 0) | \
+                (STEP_SANITIZE_LATE if sanitize_late else 0)
         rc = self.L.orc_env_step(self._h, int(action), int(sort_mode), flags,
                                  obs.ctypes.data_as(C.POINTER(C.c_float)), C.byref(rew), C.byref(term))
         if rc != 0:
@@ -192,11 +198,32 @@ class OracleEnv:
     def snapshot(self):
         ints = np.zeros(SNAP_INTS, dtype=np.int64)
         dbls = np.zeros(SNAP_DBLS, dtype=np.float64)
-        rng = np.zeros(18, dtype=np.uint64)
+        rng = np.zeros(SNAP_RNG_WORDS, dtype=np.uint64)
         self.L.orc_env_snapshot(self._h, ints.ctypes.data_as(C.POINTER(C.c_int64)),
                                 dbls.ctypes.data_as(C.POINTER(C.c_double)),
                                 rng.ctypes.data_as(C.POINTER(C.c_uint64)))
         return ints, dbls, rng
+
+    def model_fallback_action(self, use_action_masking=True):
+        """Env_3_Monolith.step(mode='model') without agents (env_monolith.py:186-221): the drawn flat action."""
+        return int(self.L.orc_env_model_fallback_action(self._h, 1 if use_action_masking else 0))
+
+    def trace_record(self):
+        """The last step as one trace record (include/mse.h MSE_TRACE_* layout)."""
+        rec = np.zeros(40, dtype=np.float64)
+        self.L.orc_env_trace_record(self._h, rec.ctypes.data_as(C.POINTER(C.c_double)))
+        return rec
+
+    def bale_count(self):
+        """The full bale_count lists (env_super.py:661-687): {material: [(size, q), ...]}."""
+        out = {}
+        for m, name in enumerate("ABCDE"):
+            cap = 4096
+            sizes, qs = np.zeros(cap, dtype=np.int64), np.zeros(cap, dtype=np.int32)
+            n = self.L.orc_env_bales(self._h, m, sizes.ctypes.data_as(C.POINTER(C.c_int64)),
+                                     qs.ctypes.data_as(C.POINTER(C.c_int32)), cap)
+            out[name] = [(int(sizes[k]), int(qs[k])) for k in range(min(n, cap))]
+        return out
 
     def random_rollout(self, n_steps, policy_seed=2024):
         return self.L.orc_env_random_rollout(self._h, int(n_steps), int(policy_seed))

@@ -162,6 +162,33 @@ def snapshot(env):
     I[SNAP["episode"]] = -1
     D[0:4] = env.accuracy_belt
     D[4:8] = env.accuracy_sorter
-    R = np.array(_rng_words(env.rng) + _rng_words(env.rng_noise) + _rng_words(env.rng_pressing),
-                 dtype=np.uint64)
+    R = np.array(_rng_words(env.rng) + _rng_words(env.rng_noise) + _rng_words(env.rng_pressing) +
+                 _rng_words(env.rng_sorting), dtype=np.uint64)
     return I, D, R
+
+
+def ledgers(env):
+    """The reference's per-env Python ledgers as plain arrays (fixture data for the opt-in trace):
+    reward_data (env_super.py:402-408, 928-946), press_actions_per_timestep (:631-637, 730-736) with material
+    names / ids / None as 0..4 / -1, and the full bale_count lists (:661-687)."""
+    rd = env.reward_data
+    out = {
+        "reward": np.asarray(rd["Reward"], dtype=np.float64).reshape(-1, 2),
+        "total": np.asarray(rd.get("Total", []), dtype=np.float64),
+        "setting": np.asarray(rd["Setting"], dtype=np.int64),
+        "belt_occupancy": np.asarray(rd["Belt_Occupancy"], dtype=np.float64),
+        "belt_proportions": np.asarray([[float(p[m]) for m in "ABCD"] for p in rd["Belt_Proportions"]], dtype=np.float64).reshape(-1, 4),
+        "true": np.asarray([rd[f"{m}_True"] for m in MATERIALS], dtype=np.int64).T.reshape(-1, 5),
+        "false": np.asarray([rd[f"{m}_False"] for m in MATERIALS], dtype=np.int64).T.reshape(-1, 5),
+    }
+    log = []
+    for code, mat in env.press_actions_per_timestep:
+        if isinstance(mat, str):
+            mat = MATERIALS.index(mat)
+        elif mat is None:
+            mat = -1
+        log.append((int(code), int(mat)))
+    out["press_log"] = np.asarray(log, dtype=np.int64).reshape(-1, 2)
+    for m in MATERIALS:
+        out[f"bales_{m}"] = np.asarray([(int(a), int(b)) for a, b in env.bale_count[m]], dtype=np.int64).reshape(-1, 2)
+    return out

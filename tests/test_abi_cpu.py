@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(L, name), f"libmse_hip.so does not export {name}"
     assert sorted(EXPORTS) == declared
-    assert L.mse_version() == 100
+    assert L.mse_version() == 200
 
 
 def test_config_struct_matches_header_and_defaults():

@@ -42,17 +42,23 @@ def _torch_reference(w, obs, mask):
     return logits, torch.log_softmax(logits, dim=1), value
 
 
-def _word(seed, g, t):
-    """policy_word of csrc/mse_policy.hip (= the random policy's stream) on the host."""
+def _fmix32(h):
     M = 0xFFFFFFFF
-    x = (seed + g * 0x9E3779B1 + t * 0x85EBCA77) & M
-    x ^= ((seed >> 32) * 0x27D4EB2F) & M
-    x ^= x >> 16
-    x = (x * 0x85EBCA6B) & M
-    x ^= x >> 13
-    x = (x * 0xC2B2AE35) & M
-    x ^= x >> 16
-    return x
+    h ^= h >> 16
+    h = (h * 0x85EBCA6B) & M
+    h ^= h >> 13
+    h = (h * 0xC2B2AE35) & M
+    h ^= h >> 16
+    return h
+
+
+def _word(seed, g, t):
+    """mse_policy_word(mse_policy_key(seed, g), t) of csrc/mse_policy_stream.h on the host."""
+    M = 0xFFFFFFFF
+    s = _fmix32((seed & M) ^ _fmix32(((seed >> 32) + 0x9E3779B9) & M))
+    key = _fmix32((s + (g & M) * 0x9E3779B1 + (g >> 32) * 0xC2B2AE3D) & M)
+    c = ((t & M) * 0x85EBCA77 + (t >> 32) * 0x27D4EB2F) & M
+    return _fmix32(c ^ key)
 
 
 @pytest.mark.parametrize("obs_dim,n_actions,n", [(29, 22, 1000), (16, 11, 333), (13, 2, 64), (29, 22, 31)])

@@ -10,7 +10,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from marl_sortingenv_amd.sharding import RolloutExchange, ShardedSortingEnv, shard_range
+from marl_sortingenv_amd.sharding import RolloutExchange, ShardedSortingEnv, shard_range, step_major, to_step_major  # noqa: F401
 
 
 class FakeEnv:
@@ -55,12 +55,24 @@ def _worker(rank, world, port, global_envs, k, ok):
         for key in exp:
             assert got[key].shape == exp[key].shape, (key, got[key].shape, exp[key].shape)
             assert torch.equal(got[key], exp[key]), key
-        # overlapped API degrades to a blocking gather without a GPU stream
-        ex = RolloutExchange(device=torch.device("cpu"))
-        ex.gather_rollout_async(FakeEnv(sh.n_local, sh.start).rollout(k, policy_seed=5)) if sh.equal_shards else None
-        if sh.equal_shards:
-            out = ex.wait()
-            assert torch.equal(out["obs"], FakeEnv(global_envs, 0).rollout(k, policy_seed=5)["obs"])
+        # rank-major layout: [R, K, n_max, ...], global env r * n_local + j at [r, :, j]; the step-major view / copy
+        rm = sh.rollout(k, policy_seed=3, layout="rank_major")
+        sizes = sh.exchange.sizes
+        assert sizes == [shard_range(global_envs, world, r)[1] for r in range(world)]
+        assert rm["obs"].shape[:3] == (world, k, max(sizes))
+        for r in range(world):
+            s0 = shard_range(global_envs, world, r)[0]
+            assert torch.equal(rm["obs"][r, :, : sizes[r]], exp["obs"][:, s0: s0 + sizes[r]])
+        assert step_major(rm["reward"]).shape[:2] == (k, world)
+        assert torch.equal(to_step_major(rm["mask"], sizes), exp["mask"])
+        # the overlapped API (blocking without a device stream), ping-pong: two tickets alive at once
+        fake = FakeEnv(sh.n_local, sh.start)
+        ex = sh.exchange
+        t1 = ex.gather_rollout_async(fake.rollout(k, policy_seed=5))
+        t2 = ex.gather_rollout_async(fake.rollout(k, policy_seed=6))
+        for tk, seed in ((t1, 5), (t2, 6)):
+            out = ex.wait(tk)
+            assert torch.equal(to_step_major(out["obs"], sizes), FakeEnv(global_envs, 0).rollout(k, policy_seed=seed)["obs"])
         ok[rank] = 1
     finally:
         dist.barrier()

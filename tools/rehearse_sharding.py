@@ -39,7 +39,7 @@ for it in range(3):
     buf = env.rollout(K, policy_seed=9)
     if shared:  # gloo: exchange host copies
         buf = {k: v.cpu() for k, v in buf.items()}
-    got = ex.gather_rollout(buf, equal_shards=(G % world == 0))
+    got = ex.gather_rollout(buf, layout="step_major")
     if rank == 0:
         ref = full.rollout(K, policy_seed=9)
         for k in ref:

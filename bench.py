@@ -118,6 +118,8 @@ def main():
     ap.add_argument("--policy", default="random", choices=["random", "mlp"],
                     help="random: the on-device masked-uniform policy (headline); mlp: the reference's actor-critic MLP "
                          "evaluated inside the rollout kernel (MaskablePPO-shaped collection, BASELINE.json configs[3])")
+    ap.add_argument("--precision", default="auto", choices=["auto", "f32", "f16x3"],
+                    help="--policy mlp: arithmetic of the policy's matrix products (include/mse.h mse_policy_set_precision)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
     args = ap.parse_args()
@@ -159,7 +161,7 @@ def main():
 
     collector = None
     if args.policy == "mlp":
-        collector = M.FusedPolicyRollout(env, M.MlpPolicy.random_init(env.obs_dim, env.num_actions, seed=7, device=dev), chunk)
+        collector = M.FusedPolicyRollout(env, M.MlpPolicy.random_init(env.obs_dim, env.num_actions, seed=7, device=dev, precision=args.precision), chunk)
 
     def run(n_steps, events=None):
         if collector is not None:
@@ -266,7 +268,7 @@ def main():
                 "envs_per_gpu": n, "global_envs": n * world, "max_steps": args.max_steps,
                 "balesize": 200, "noise_sorting": args.noise,
                 "policy": "on-device masked-uniform, seed 2024" if args.policy == "random" else
-                          "actor-critic MLP 2x32 tanh (random-init weights) with masked categorical sampling, inside the rollout kernel",
+                          f"actor-critic MLP 2x32 tanh (random-init weights, matrix products {collector.policy.precision}) with masked categorical sampling, inside the rollout kernel",
                 "steps_per_launch": min(chunk, args.steps), "outputs": "none (diagnostic)" if args.no_outputs else
                 "obs f32[K,N,D], mask u8[K,N,A], action i32, reward f32, done u8 per step",
                 "parallelism": f"env-index sharding x{world}, no data-path collective" +

@@ -273,9 +273,35 @@ typedef struct mse_policy mse_policy;
 int64_t mse_policy_num_weights(int obs_dim, int n_actions);
 int mse_policy_create(mse_policy **out, int obs_dim, int n_actions, const float *weights_host, int device_id);
 int mse_policy_destroy(mse_policy *policy);
+/* Arithmetic of the matrix products: 1 = exact f32 (v_mfma_f32_32x32x2_f32, an fmaf chain); 2 = "f16x3": every f32
+ * operand split into two f16 parts carrying 22 bits, three f16 MFMAs per product with f32 accumulation (logits within
+ * ~1e-6 of the exact form, 5x the matrix rate; needs every folded weight below 65 504); 0 = f16x3 when the weights
+ * allow it, else f32 (the default).  mse_policy_precision reports which one is in effect (1 | 2). */
+int mse_policy_set_precision(mse_policy *policy, int mode);
+int mse_policy_precision(const mse_policy *policy);
 int mse_policy_forward(mse_policy *policy, int64_t n, int64_t index_offset, const float *obs_dev, const uint8_t *mask_dev,
                        uint64_t seed, uint64_t t, int deterministic, int32_t *action_out, float *logp_out,
                        float *value_out, float *logits_out, void *stream);
+
+/* ---- SURVEY 8f ranks 1 + 2 fused: K steps of policy forward + env transition in ONE launch -------------------------
+ * The consumer loop of the reference's training (SB3's collect_rollouts inside model.learn, src/training.py:191, with
+ * the policy of src/training.py:115-131): per step k and env i
+ *     observation / action mask / episode-start flag of the state the action is taken from   (obs_out f32[K,N,D],
+ *                                                       mask_out u8[K,N,A], episode_start_out u8[K,N])
+ *     action, log-probability, value = policy(observation, mask)   (sampled with the engine's stream at step counter
+ *                                                       t + k, or argmax with deterministic != 0: actions_out i32[K,N],
+ *                                                       logp_out f32[K,N], value_out f32[K,N])
+ *     reward of the transition under that action, auto-reset on termination                  (reward_out f32[K,N])
+ * i.e. the rows of SB3's MaskableRolloutBuffer, plus last_value_out f32[N] (the value of the state after the last
+ * step, the bootstrap of compute_returns_and_advantage) and last_done_out u8[N].  Any output may be NULL.  The
+ * observation never leaves the wave's registers between env_step and the policy's MFMA chain.  Bit-identical to
+ * alternating mse_policy_forward and mse_step with the same seed and step counter.
+ *   sort_mode_dev i32[N] or NULL: Env_2's per-env sorting decision (NULL = sorting_rules()).
+ *   flags: MSE_STEP_UNMASKED, MSE_STEP_CHECK_OVERFLOW.  Needs auto_reset=1; advances the policy step counter by K. */
+int mse_rollout_policy(mse_env *env, mse_policy *policy, int32_t k_steps, uint64_t seed, int deterministic,
+                       const int32_t *sort_mode_dev, uint32_t flags, float *obs_out, uint8_t *mask_out,
+                       int32_t *actions_out, float *logp_out, float *value_out, float *reward_out,
+                       uint8_t *episode_start_out, float *last_value_out, uint8_t *last_done_out, void *stream);
 
 #ifdef __cplusplus
 }

@@ -11,7 +11,7 @@ from .config import KIND_BY_NAME, NUM_ACTIONS, OBS_DIM, SortingEnvConfig
 
 __all__ = [
     "BatchedSortingEnv", "Env_1_Sorting", "Env_2_Pressing", "Env_3_Monolith", "SortingVecEnv",
-    "ShardedSortingEnv", "MlpPolicy", "PolicyRolloutCollector", "SortingEnvConfig", "MseError", "build_library", "load_library", "library_path",
+    "ShardedSortingEnv", "MlpPolicy", "PolicyRolloutCollector", "FusedPolicyRollout", "SortingEnvConfig", "MseError", "build_library", "load_library", "library_path",
     "KIND_BY_NAME", "OBS_DIM", "NUM_ACTIONS", "MSE_ENV_SORT", "MSE_ENV_PRESS", "MSE_ENV_MONO",
     "MSE_STEP_UNMASKED", "MSE_STEP_CHECK_OVERFLOW", "MSE_SNAP_INTS",
 ]
@@ -27,9 +27,9 @@ def __getattr__(name):  # torch-dependent front-ends are imported on first use
     if name == "SortingVecEnv":
         from .vec_env import SortingVecEnv
         return SortingVecEnv
-    if name == "PolicyRolloutCollector":
-        from .collector import PolicyRolloutCollector
-        return PolicyRolloutCollector
+    if name in ("PolicyRolloutCollector", "FusedPolicyRollout"):
+        from . import collector
+        return getattr(collector, name)
     if name == "MlpPolicy":
         from .policy import MlpPolicy
         return MlpPolicy

@@ -19,7 +19,7 @@ EXPORTS = [
     "mse_step", "mse_action_masks", "mse_rollout", "mse_sample_actions", "mse_rule_actions", "mse_get_state", "mse_set_state",
     "mse_error_count", "mse_algorithmic_bytes_per_step", "mse_tie_window",
     "mse_sort_agent_obs", "mse_policy_num_weights", "mse_policy_create", "mse_policy_destroy", "mse_policy_forward",
-    "mse_get_policy_step", "mse_set_policy_step", "mse_model_actions", "mse_trace_begin", "mse_trace_end", "mse_press_agent_obs",
+    "mse_get_policy_step", "mse_set_policy_step", "mse_model_actions", "mse_trace_begin", "mse_trace_end", "mse_press_agent_obs", "mse_rollout_policy", "mse_policy_set_precision", "mse_policy_precision",
 ]
 
 _other_libs: dict = {}
@@ -113,7 +113,10 @@ def load_library(path: str | None = None) -> C.CDLL:
     L.mse_policy_num_weights.restype = i64
     L.mse_policy_create.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.POINTER(C.c_float), C.c_int]
     L.mse_policy_destroy.argtypes = [vp]
+    L.mse_policy_set_precision.argtypes = [vp, C.c_int]
+    L.mse_policy_precision.argtypes = [vp]
     L.mse_policy_forward.argtypes = [vp, i64, i64, vp, vp, u64, u64, C.c_int, vp, vp, vp, vp, vp]
+    L.mse_rollout_policy.argtypes = [vp, vp, i32, u64, C.c_int, vp, u32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     if path is None:
         _lib = L
     else:

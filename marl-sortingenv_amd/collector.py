@@ -6,7 +6,11 @@ halves on the device - `mse_policy_forward` then `mse_step` - and fills buffers 
 `MaskableRolloutBuffer` ([K, N, ...]: observations, action masks, actions, log-probabilities, values, rewards,
 episode starts), so a learner can consume them without a host copy.  For `Env_2_Pressing` an optional sorting policy
 (13 -> 2, evaluated deterministically on `mse_sort_agent_obs`, env_2_press.py:101-104) plays the pre-trained sorting
-agent.  Two launches per step; the fully fused K-step kernel exists for the built-in policies (`rollout`).
+agent.  Two launches per step.
+
+`FusedPolicyRollout` is the same collection in ONE launch per rollout (`mse_rollout_policy`): the policy forward runs
+inside the rollout kernel, the observation never leaves the wave's registers between the env transition and the
+policy's MFMA chain.  Its buffers are bit-identical to `PolicyRolloutCollector`'s for the same seed.
 """
 from __future__ import annotations
 
@@ -68,3 +72,54 @@ class PolicyRolloutCollector:
         last = self.policy.forward(env.obs, env.mask, seed=self.seed, t=self.t, deterministic=True,
                                    index_offset=env.index_offset)
         return dict(b, last_values=last["value"], last_dones=self._last_done.clone())
+
+
+class FusedPolicyRollout:
+    """K steps of policy forward + env transition per launch (`mse_rollout_policy`): MaskableRolloutBuffer-shaped
+    device tensors [K, N, ...].  `sort_mode`: Env_2's per-env sorting decisions (None = the reference's rule)."""
+
+    def __init__(self, env: BatchedSortingEnv, policy: MlpPolicy, n_steps: int, seed: int = 2024,
+                 sort_mode: Optional[torch.Tensor] = None):
+        if policy.obs_dim != env.obs_dim or policy.n_actions != env.num_actions:
+            raise ValueError("policy dimensions do not match the env")
+        if not env.auto_reset:
+            raise ValueError("collection needs auto_reset=True (episodes end inside a rollout)")
+        self.env, self.policy, self.n_steps, self.seed = env, policy, int(n_steps), int(seed)
+        self.sort_mode = None if sort_mode is None else sort_mode.to(device=env.device, dtype=torch.int32).contiguous()
+        n, K, dev = env.num_envs, self.n_steps, env.device
+        self.buffers = {
+            "observations": torch.empty((K, n, env.obs_dim), dtype=torch.float32, device=dev),
+            "action_masks": torch.empty((K, n, env.num_actions), dtype=torch.uint8, device=dev),
+            "actions": torch.empty((K, n), dtype=torch.int32, device=dev),
+            "log_probs": torch.empty((K, n), dtype=torch.float32, device=dev),
+            "values": torch.empty((K, n), dtype=torch.float32, device=dev),
+            "rewards": torch.empty((K, n), dtype=torch.float32, device=dev),
+            "episode_starts": torch.empty((K, n), dtype=torch.uint8, device=dev),
+            "last_values": torch.empty((n,), dtype=torch.float32, device=dev),
+            "last_dones": torch.empty((n,), dtype=torch.uint8, device=dev),
+        }
+
+    def collect(self, n_steps: Optional[int] = None, deterministic: bool = False, use_action_masking: bool = True,
+                check_overflow: bool = False) -> dict:
+        """One launch.  n_steps <= the buffers' K (a shorter rollout fills the first rows).  The env's own obs / mask
+        tensors are not refreshed (the state is; call env.refresh_outputs() to step it by hand afterwards)."""
+        import ctypes as C
+
+        from ._lib import MSE_STEP_CHECK_OVERFLOW, MSE_STEP_UNMASKED, check
+
+        K = self.n_steps if n_steps is None else int(n_steps)
+        if not 1 <= K <= self.n_steps:
+            raise ValueError("n_steps must be in [1, the collector's K]")
+        env, b = self.env, self.buffers
+        flags = (0 if use_action_masking else MSE_STEP_UNMASKED) | (MSE_STEP_CHECK_OVERFLOW if check_overflow else 0)
+
+        def ptr(x):
+            return None if x is None else C.c_void_p(x.data_ptr())
+
+        with torch.cuda.device(env.device):
+            check(env.L.mse_rollout_policy(env._h, self.policy._h, K, self.seed, 1 if deterministic else 0,
+                                           ptr(self.sort_mode), flags, ptr(b["observations"]), ptr(b["action_masks"]),
+                                           ptr(b["actions"]), ptr(b["log_probs"]), ptr(b["values"]), ptr(b["rewards"]),
+                                           ptr(b["episode_starts"]), ptr(b["last_values"]), ptr(b["last_dones"]),
+                                           env._stream()))
+        return b

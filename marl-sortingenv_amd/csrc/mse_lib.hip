@@ -4,6 +4,7 @@
 //   hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -std=c++17 -fPIC -shared -Iinclude \
 //         marl-sortingenv_amd/csrc/mse_lib.hip -o marl-sortingenv_amd/libmse_hip.so
 #include "mse_device.h"
+#include "mse_policy_device.h"
 
 #include "mse.h"
 
@@ -838,6 +839,213 @@ __global__ __launch_bounds__(kRingThreads) void k_rollout_ring(Params P, uint4 *
     }
 }
 
+
+// ==========================================================================================
+// Learned-policy rollout: policy forward + env transition fused, K steps per launch  (DESIGN.md "Policy rollout")
+//
+// The consumer loop of the reference's training (SB3 collect_rollouts inside model.learn, src/training.py:191;
+// policy of src/training.py:115-131) alternates policy(obs, mask) -> action and env.step(action).  Here one wave owns
+// 64 envs for the whole launch and does both: the observation it computed stays in registers, is laid out as the
+// MFMA B operand with one v_permlane32_swap per register pair (lanes 0-31 / 32-63 are the two 32-env tiles), goes
+// through the actor-critic MLP on the f32 matrix cores (msep::policy_tile), and the sampled action feeds the same
+// lane's env_dynamics.  Per step the wave writes a MaskableRolloutBuffer row: the observation and mask the action was
+// taken from, the episode-start flag, action, log-probability, value and the step's reward.  No barrier in the step
+// loop: the waves of a workgroup share only the read-only weight / table images in LDS, so with several waves per SIMD
+// one wave's MFMA chain runs under another's dynamics.
+// LDS: [weights][tables][per wave: obs tile (the mask tile reuses it) | bale ledger]
+// ==========================================================================================
+template <int KIND, int TILES>
+struct PolLayout {
+    static constexpr int D = Dims<KIND>::D, A = Dims<KIND>::A;
+    static constexpr int ENVS = 32 * TILES;                          // envs per wave
+    static constexpr int weight_bytes = msep::kLdsFloats * 4;
+    static constexpr int tile_bytes = (ENVS * D * 4 + 15) / 16 * 16; // >= the ENVS x A mask tile
+    static constexpr int bale_bytes = 5 * ENVS * 16;
+    static constexpr int wave_bytes = tile_bytes + bale_bytes;
+};
+
+// A wave's ROWS observation rows (D floats each, one per lane) / mask rows through its private LDS tile to global
+// memory as 16-byte pieces; ROWS = 32 | 64.  Same scheme as stage_and_store, for a wave-sized tile.
+template <int D, int ROWS>
+__device__ __forceinline__ void wave_store_rows_f32(float *ltile, const float *o, float *g, int n_valid, int lane)
+{
+    if (lane < ROWS) {
+#pragma unroll
+        for (int j = 0; j < D; ++j) ltile[lane * D + j] = o[j];
+    }
+    __builtin_amdgcn_wave_barrier();
+    constexpr int NQ = ROWS * D / 4; // 16-byte pieces of a full tile
+    if (n_valid == ROWS && (reinterpret_cast<uintptr_t>(g) & 15u) == 0) {
+        const float4 *src = reinterpret_cast<const float4 *>(ltile);
+        float4 *dst = reinterpret_cast<float4 *>(g);
+        constexpr int NR = (NQ + 63) / 64;
+        float4 buf[NR];
+#pragma unroll
+        for (int j = 0; j < NR; ++j) buf[j] = src[(lane + 64 * j) < NQ ? lane + 64 * j : 0];
+#pragma unroll
+        for (int j = 0; j < NR; ++j)
+            if (lane + 64 * j < NQ) store_stream(dst + lane + 64 * j, buf[j]);
+    } else {
+        for (int q = lane; q < n_valid * D; q += 64) g[q] = ltile[q];
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+template <int A, int ROWS>
+__device__ __forceinline__ void wave_store_rows_mask(uint8_t *ltile, uint32_t mbits, uint8_t *g, int n_valid, int lane)
+{
+    if (lane < ROWS) {
+#pragma unroll
+        for (int j = 0; j < A; ++j) ltile[lane * A + j] = (uint8_t)((mbits >> j) & 1u);
+    }
+    __builtin_amdgcn_wave_barrier();
+    constexpr int NQ = ROWS * A / 16;
+    if (n_valid == ROWS && (ROWS * A) % 16 == 0 && NQ <= 64 && (reinterpret_cast<uintptr_t>(g) & 15u) == 0) {
+        const uint4 v = reinterpret_cast<const uint4 *>(ltile)[lane < NQ ? lane : 0];
+        if (lane < NQ) store_stream(reinterpret_cast<uint4 *>(g) + lane, v);
+    } else {
+        for (int q = lane; q < n_valid * A; q += 64) g[q] = ltile[q];
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+// TILES = 2: a wave owns 64 envs, one per lane, as two MFMA tiles (lanes 0-31 / 32-63).
+// TILES = 1: a wave owns 32 envs in lanes 0-31 (lanes 32-63 only carry the other k-half of the MFMA operands): twice
+//            the waves for the same batch - the shape for batches that would otherwise leave one wave per SIMD, where
+//            a single wave issues one vector instruction per ~5 cycles and a second wave's come for free.
+template <int KIND, bool NOISE, int TILES, bool F16X3>
+__global__ __launch_bounds__(512) void k_rollout_policy(Params P, uint4 *__restrict__ planes,
+                                                        const uint32_t *__restrict__ table_image,
+                                                        const float *__restrict__ weight_blob, int k_steps,
+                                                        uint64_t policy_seed, uint64_t policy_t0, int deterministic,
+                                                        const int *__restrict__ sort_mode, uint32_t flags,
+                                                        float *__restrict__ obs_out, uint8_t *__restrict__ mask_out,
+                                                        int *__restrict__ actions_out, float *__restrict__ logp_out,
+                                                        float *__restrict__ value_out, float *__restrict__ reward_out,
+                                                        uint8_t *__restrict__ start_out,
+                                                        float *__restrict__ last_value_out,
+                                                        uint8_t *__restrict__ last_done_out)
+{
+    using L = PolLayout<KIND, TILES>;
+    constexpr int D = L::D, A = L::A, NR = msep::regs_for_actions(A), ENVS = L::ENVS;
+    uint8_t *lds = reinterpret_cast<uint8_t *>(mse_dyn_lds);
+    float *lw = reinterpret_cast<float *>(lds);
+    uint32_t *ltab = reinterpret_cast<uint32_t *>(lds + L::weight_bytes);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, n_waves = blockDim.x >> 6;
+    const int table_bytes = P.table_words * 4;
+    uint8_t *lwave = lds + L::weight_bytes + table_bytes + wave * L::wave_bytes;
+    uint4 *lbale = reinterpret_cast<uint4 *>(lwave + L::tile_bytes);
+    const long long wave_row0 = ((long long)blockIdx.x * n_waves + wave) * ENVS;
+    const bool wave_active = wave_row0 < P.n_pad; // the planes are padded to 256 envs: the last workgroup may overhang
+    const bool env_lane = lane < ENVS;            // TILES = 1: lanes 32-63 hold no env
+    const long long i = (wave_active && env_lane) ? wave_row0 + lane : 0;
+    const bool live = wave_active && env_lane && i < P.n;
+    long long rem = P.n - wave_row0;
+    const int n_valid = rem >= ENVS ? ENVS : (rem > 0 ? (int)rem : 0);
+
+    msep_copy_image(lw, weight_blob, F16X3, tid, blockDim.x);
+    for (int w = tid; w < P.table_words / 4; w += blockDim.x)
+        reinterpret_cast<uint4 *>(ltab)[w] = reinterpret_cast<const uint4 *>(table_image)[w];
+    const BaleRef bales{lbale + (env_lane ? lane : 0), ENVS};
+    if (P.track_bales && wave_active && env_lane) {
+#pragma unroll
+        for (int m = 0; m < 5; ++m) lbale[m * ENVS + lane] = planes[(long long)(PL_BALE0 + m) * P.n_pad + i];
+    }
+    Env e;
+    int sm = -1;
+    load_env<KIND, NOISE>(e, planes, P, i); // padded planes: safe for every lane of an active wave (idle lanes read env 0)
+    if (KIND == 2 && sort_mode != nullptr && live) sm = sort_mode[i];
+    __syncthreads();
+    if (!wave_active) return;
+    __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): nothing but stores inside the step loop
+    const Tables tb = tables_at(ltab, P);
+    msep::lds_f4 wl = (msep::lds_f4)(__attribute__((address_space(3))) float *)lw;
+
+    // the observation and mask of the current state (what reset / the previous launch left)
+    float o[32];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) o[j] = 0.0f;
+    uint32_t mbits = 0;
+    if (live) {
+        int k0[4];
+        container_purity_k(e, k0);
+        env_obs<KIND>(e, P, tb, k0, o);
+        mbits = action_mask_bits<KIND>(e, P);
+    }
+    // policy stream keys of the env(s) this lane serves as an MFMA column: tile t = envs 32 t .. 32 t + 31 of the wave
+    const int h = lane >> 5, col = lane & 31;
+    const uint32_t key0 = mse_policy_key(policy_seed, (uint64_t)(P.index_offset + wave_row0 + col));
+    const uint32_t key1 = mse_policy_key(policy_seed, (uint64_t)(P.index_offset + wave_row0 + 32 + col));
+
+    // action_masks() bits of env -> bit r: the action of accumulator register r of half h is legal
+    auto legal_of = [&](uint32_t env_bits) -> uint32_t {
+        const uint32_t t = env_bits >> (4 * h);
+        return (t & 0xFu) | ((t >> 4) & 0xF0u) | ((t >> 8) & 0xF00u) | ((t >> 12) & 0xF000u);
+    };
+
+    int last_done = 0;
+    for (int s = 0; s <= k_steps; ++s) {
+        const bool tail = s == k_steps; // one more forward after the last step: the bootstrap value of the final state
+        const long long srow = (long long)s * P.n + wave_row0;
+        if (!tail) {
+            // the row the action is taken from (MaskableRolloutBuffer: observations, action_masks, episode_starts)
+            if (obs_out != nullptr) wave_store_rows_f32<D, ENVS>(reinterpret_cast<float *>(lwave), o, obs_out + srow * D, n_valid, lane);
+            if (mask_out != nullptr) wave_store_rows_mask<A, ENVS>(lwave, mbits, mask_out + srow * A, n_valid, lane);
+            if (live && start_out != nullptr)
+                __builtin_nontemporal_store((uint8_t)(e.step == 0 ? 1 : 0), &start_out[(long long)s * P.n + i]);
+        }
+        // ---- policy.  swap(o[2q], o[2q+1]) = {tile 0's k-step q operand, tile 1's}: lanes 32-63 of tile 0 get the
+        // odd entries of the envs in lanes 0-31, lanes 0-31 of tile 1 the even entries of the envs in lanes 32-63
+        float x0[16], x1[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(o[2 * q]), __float_as_uint(o[2 * q + 1]), false, false);
+            x0[q] = __uint_as_float(r[0]);
+            x1[q] = __uint_as_float(r[1]);
+        }
+        // without masking (plain PPO on the unmasked env) the policy samples from the whole action space and the
+        // step sanitises; the recorded mask row is action_masks() either way
+        uint32_t mb0, mb1;
+        msep::both_halves_u32((flags & MSE_STEP_UNMASKED) ? ((1u << A) - 1u) : mbits, mb0, mb1);
+        const uint64_t t = policy_t0 + (uint64_t)s;
+        const bool det = deterministic != 0 || tail;
+        const msep::TileOut p0 = msep::policy_tile<NR, F16X3>(wl, lane, x0, legal_of(mb0), det, mse_policy_word(key0, t), nullptr);
+        int a = p0.action;
+        float logp = p0.logp, value = p0.value;
+        if (TILES == 2) {
+            const msep::TileOut p1 = msep::policy_tile<NR, F16X3>(wl, lane, x1, legal_of(mb1), det, mse_policy_word(key1, t), nullptr);
+            a = h ? p1.action : a; // lane l is env l: tile l >> 5, column l & 31 (results are valid in both halves)
+            logp = h ? p1.logp : logp;
+            value = h ? p1.value : value;
+        }
+        if (tail) {
+            if (live && last_value_out != nullptr) last_value_out[i] = value;
+            if (live && last_done_out != nullptr) last_done_out[i] = (uint8_t)last_done;
+            break;
+        }
+        // ---- the env transition under that action
+        if (live) {
+            int k[4];
+            StepResult r = env_step<KIND, NOISE, false>(e, P, tb, a, sm, flags, bales, k, o);
+            if (__builtin_expect(r.done != 0, 0)) {
+                auto_reset_env(e, P, tb, bales, k);
+                env_obs<KIND>(e, P, tb, k, o);
+            }
+            mbits = action_mask_bits<KIND>(e, P);
+            last_done = r.done;
+            const long long at = (long long)s * P.n + i;
+            if (actions_out != nullptr) __builtin_nontemporal_store(a, &actions_out[at]);
+            if (logp_out != nullptr) __builtin_nontemporal_store(logp, &logp_out[at]);
+            if (value_out != nullptr) __builtin_nontemporal_store(value, &value_out[at]);
+            if (reward_out != nullptr) __builtin_nontemporal_store((float)r.reward, &reward_out[at]);
+        }
+    }
+    if (live) store_env<KIND, NOISE>(e, planes, P, i, false);
+    if (P.track_bales && env_lane) {
+#pragma unroll
+        for (int m = 0; m < 5; ++m) planes[(long long)(PL_BALE0 + m) * P.n_pad + i] = lbale[m * ENVS + lane];
+    }
+}
+
 template <int KIND>
 __global__ __launch_bounds__(kBlock) void k_reset(Params P, uint4 *__restrict__ planes,
                                                   const uint32_t *__restrict__ table_image,
@@ -1484,6 +1692,44 @@ static void launch_rollout(mse_env *h, hipStream_t s, int k_steps, uint64_t poli
 #undef MSE_LAUNCH_ROLLOUT
 }
 
+template <int KIND>
+static int launch_rollout_policy(mse_env *h, const mse_policy *pol, hipStream_t s, int k_steps, uint64_t seed,
+                                 int deterministic, const int32_t *sort_mode, uint32_t flags, float *obs, uint8_t *mask,
+                                 int32_t *actions, float *logp, float *value, float *rew, uint8_t *start,
+                                 float *last_value, uint8_t *last_done)
+{
+    // Shape: eight waves per workgroup, two per SIMD.  While 32-env waves leave every CU at most one workgroup's worth
+    // (n <= 256 envs x CUs) a wave owns 32 envs - at that size 64-env waves would run one per SIMD, at a vector
+    // instruction per ~5 cycles; beyond, 64 envs.  The exact-f32 form only exists in the 64-env shape.
+    int cus = 256;
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, h->device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+    }
+    const bool f16 = pol->use_f16();
+    const int tiles = (f16 && h->P.n <= (long long)256 * cus) ? 1 : 2;
+    // (the exact-f32 form below that size: four 64-env waves per workgroup, so that every CU gets one)
+    const int n_waves = (!f16 && h->P.n <= (long long)256 * cus) ? 4 : 8;
+    const long long envs_per_wg = 32LL * tiles * n_waves;
+    const dim3 grid((unsigned)((h->P.n + envs_per_wg - 1) / envs_per_wg)), block((unsigned)(64 * n_waves));
+    const size_t wave_bytes = tiles == 1 ? PolLayout<KIND, 1>::wave_bytes : PolLayout<KIND, 2>::wave_bytes;
+    const size_t lds = (size_t)msep::kLdsFloats * 4u + (size_t)h->P.table_words * 4u + (size_t)n_waves * wave_bytes;
+    if (lds > (size_t)160 * 1024) return MSE_ERR_UNSUPPORTED_CONFIG;
+#define MSE_LAUNCH_RP(NOISE, TILES, F16)                                                                             \
+    hipLaunchKernelGGL((k_rollout_policy<KIND, NOISE, TILES, F16>), grid, block, lds, s, h->P, h->planes, h->tables, \
+                       pol->blob, k_steps, seed, h->policy_t, deterministic, sort_mode, flags, obs, mask, actions,   \
+                       logp, value, rew, start, last_value, last_done)
+    if (!f16) {
+        if (h->noise_on) MSE_LAUNCH_RP(true, 2, false); else MSE_LAUNCH_RP(false, 2, false);
+    } else if (tiles == 1) {
+        if (h->noise_on) MSE_LAUNCH_RP(true, 1, true); else MSE_LAUNCH_RP(false, 1, true);
+    } else {
+        if (h->noise_on) MSE_LAUNCH_RP(true, 2, true); else MSE_LAUNCH_RP(false, 2, true);
+    }
+#undef MSE_LAUNCH_RP
+    return MSE_OK;
+}
+
 extern "C" {
 
 int mse_version(void) { return MSE_VERSION; }
@@ -1816,6 +2062,40 @@ int mse_rollout(mse_env *h, int32_t k_steps, uint64_t policy_seed, const int32_t
     case 2: launch_rollout<2>(h, s, k_steps, policy_seed, sort_mode, flags, actions_out, obs_out, reward_out, done_out, mask_out); break;
     default: launch_rollout<3>(h, s, k_steps, policy_seed, sort_mode, flags, actions_out, obs_out, reward_out, done_out, mask_out); break;
     }
+    MSE_CHECK_LAUNCH();
+    h->policy_t += (uint64_t)k_steps;
+    return MSE_OK;
+}
+
+int mse_rollout_policy(mse_env *h, mse_policy *pol, int32_t k_steps, uint64_t seed, int deterministic,
+                       const int32_t *sort_mode, uint32_t flags, float *obs_out, uint8_t *mask_out, int32_t *actions_out,
+                       float *logp_out, float *value_out, float *reward_out, uint8_t *episode_start_out,
+                       float *last_value_out, uint8_t *last_done_out, void *stream)
+{
+    if (!h || !pol) return fail(MSE_ERR_INVALID_ARGUMENT, "env/policy is NULL");
+    if (!h->seeded) return fail(MSE_ERR_NOT_RESET, "mse_rollout_policy before mse_reset(seeds)");
+    if (k_steps < 1) return fail(MSE_ERR_INVALID_ARGUMENT, "k_steps must be >= 1");
+    if (!h->P.auto_reset) return fail(MSE_ERR_INVALID_ARGUMENT, "mse_rollout_policy needs auto_reset=1");
+    if (h->trace_rec != nullptr)
+        return fail(MSE_ERR_INVALID_ARGUMENT, "a trace is attached (mse_trace_begin): only mse_step records, end it first");
+    if (flags & ~(MSE_STEP_UNMASKED | MSE_STEP_CHECK_OVERFLOW))
+        return fail(MSE_ERR_INVALID_ARGUMENT, "unknown rollout flag");
+    if (pol->d_in != mse_obs_dim(h) || pol->n_act != mse_num_actions(h))
+        return fail(MSE_ERR_INVALID_ARGUMENT, "the policy's observation / action dimensions do not match the env kind");
+    if (pol->device != h->device) return fail(MSE_ERR_INVALID_ARGUMENT, "policy and env live on different devices");
+    if ((obs_out && !aligned16(obs_out)) || (mask_out && !aligned16(mask_out)))
+        return fail(MSE_ERR_ALIGNMENT, "obs_out / mask_out must be 16-byte aligned");
+    if (h->literal)
+        return fail(MSE_ERR_UNSUPPORTED_CONFIG, "mse_rollout_policy serves the integer draw path only (literal_choice / "
+                                                "input_batch_size > 127 handles: alternate mse_policy_forward and mse_step)");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    int rc;
+    switch (h->P.env_kind) {
+    case 1: rc = launch_rollout_policy<1>(h, pol, s, k_steps, seed, deterministic, sort_mode, flags, obs_out, mask_out, actions_out, logp_out, value_out, reward_out, episode_start_out, last_value_out, last_done_out); break;
+    case 2: rc = launch_rollout_policy<2>(h, pol, s, k_steps, seed, deterministic, sort_mode, flags, obs_out, mask_out, actions_out, logp_out, value_out, reward_out, episode_start_out, last_value_out, last_done_out); break;
+    default: rc = launch_rollout_policy<3>(h, pol, s, k_steps, seed, deterministic, sort_mode, flags, obs_out, mask_out, actions_out, logp_out, value_out, reward_out, episode_start_out, last_value_out, last_done_out); break;
+    }
+    if (rc != MSE_OK) return fail(rc, "the policy rollout kernel's LDS image does not fit this config's tables");
     MSE_CHECK_LAUNCH();
     h->policy_t += (uint64_t)k_steps;
     return MSE_OK;

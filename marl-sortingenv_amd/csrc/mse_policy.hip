@@ -1,48 +1,25 @@
-// Batched forward of the reference's actor-critic policy with masked categorical sampling, on the matrix cores.
-//
-// The policy SB3 builds for the reference (src/training.py:115: net_arch=dict(pi=[32, 32], vf=[32, 32]), default
-// tanh activations, MaskableActorCriticPolicy): two separate 2x32 tanh MLPs on the flattened observation, a linear
-// action head (32 -> A) and a linear value head (32 -> 1); invalid actions get logit -1e8 before the softmax
-// (sb3_contrib MaskableCategorical).  This is SURVEY 8f rank 2: the step on the caller's side of env.step().
-//
-// One wavefront serves a tile of 32 envs with v_mfma_f32_32x32x2_f32 (f32 in, f32 accumulate: the result is an
-// fmaf chain, only the summation order differs from a CPU reference).  Orientation: outputs (hidden units or
-// actions) are the rows, envs are the columns.  C/D layout: lane l = (half h = l >> 5, env j = l & 31), register
-// r holds row (r & 3) + 8 (r >> 2) + 4 h.  A product that sums over those rows can take the accumulator
-// registers straight as its B operand, one register per k-step, provided the A operand (the weights) is loaded
-// in the matching k order - so the three layers chain with no lane movement, no LDS and no transposes: the
-// weights of every layer are loaded into registers once per wave in that permuted order.
-// gfx950 only.
+// Batched forward of the reference's actor-critic policy with masked categorical sampling, on the matrix cores:
+// the standalone launch (mse_policy_forward).  The network, its MFMA layout and the sampling rule live in
+// mse_policy_device.h (one device function per 32-env tile, shared with the fused learned-policy rollout kernel of
+// mse_lib.hip); this file holds the kernel that feeds it from observation / mask tensors, the host-side packing of
+// torch.nn.Linear weights into MFMA operand order, and the C ABI.  gfx950 only.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
 #include <cstdint>
+#include <cstring>
 #include <string>
 #include <vector>
 
 #include "mse.h"
+#include "mse_policy_device.h"
 #include "mse_policy_stream.h"
 
 int mse_internal_fail(int status, const char *msg); // mse_lib.hip: sets mse_last_error()
 
 namespace {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-constexpr int kHidden = 32;
-constexpr int kTile = 32; // envs per MFMA tile
-constexpr int kPackedFloats = 11 * 16 * 64 + 4; // pack_weights(): eleven [16][64] arrays, then val_b (padded to 16 B)
-
-__device__ __forceinline__ int row_of(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
-
-// tanh(x) = 1 - 2 / (2^(2 x log2 e) + 1): v_exp_f32 + v_rcp_f32, absolute error ~2e-7
-__device__ __forceinline__ float fast_tanh(float x)
-{
-    const float t = __builtin_amdgcn_exp2f(x * 2.88539008177792681472f);
-    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(t + 1.0f);
-}
-
-__device__ __forceinline__ float xhalf(float v) { return __shfl_xor(v, 32); } // the other half's value for this env
-__device__ __forceinline__ int xhalf_i(int v) { return __shfl_xor(v, 32); }
+using namespace msep;
 
 struct PolicyArgs {
     long long n;
@@ -52,30 +29,20 @@ struct PolicyArgs {
     unsigned long long seed, t;
 };
 
-// blob: the weights packed by pack_weights() below in MFMA operand order
+// blob: the weights packed by pack_weights() below.  One wave per tile of 32 envs, grid-stride over the tiles.
+template <int NR, bool F16X3>
 __global__ __launch_bounds__(512) void k_policy_mlp(PolicyArgs P, const float *__restrict__ blob,
                                                     const float *__restrict__ obs, const uint8_t *__restrict__ mask,
                                                     int *__restrict__ action_out, float *__restrict__ logp_out,
                                                     float *__restrict__ value_out, float *__restrict__ logits_out)
 {
     const int lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31;
-    // The packed weights (A operands and bias accumulators in register order, [array][register s][lane]) are
-    // copied to LDS once per workgroup and read from there layer by layer: a wave that kept all eleven arrays in
-    // registers needs 308 VGPRs (one wave per SIMD) and every wave would pull the 45 KB through L2 by itself -
-    // that transfer, not the MFMAs, was the whole kernel time of the first version.
+    // the packed weights are copied to LDS once per workgroup and read from there layer by layer (16-byte reads):
+    // held in registers they would cost a wave ~100 VGPRs and every wave its own trip through L2
     extern __shared__ float wlds[];
-    for (int w = threadIdx.x; w < kPackedFloats / 4; w += blockDim.x)
-        reinterpret_cast<float4 *>(wlds)[w] = reinterpret_cast<const float4 *>(blob)[w];
+    msep_copy_image(wlds, blob, F16X3, threadIdx.x, blockDim.x);
     __syncthreads();
-    // volatile: re-read per tile (one conflict-free ds_read_b32 per operand) instead of 176 registers held per wave,
-    // so that two waves fit on a SIMD and one's MFMA chain runs under the other's tanh / softmax work
-    typedef __attribute__((address_space(3))) const volatile float *wptr; // stays a ds_read with an immediate offset
-    wptr wbase = (wptr)(__attribute__((address_space(3))) float *)wlds + lane;
-    wptr a1 = wbase + (0 * 16) * 64, a2 = wbase + (1 * 16) * 64, a3 = wbase + (2 * 16) * 64;
-    wptr v1 = wbase + (3 * 16) * 64, v2 = wbase + (4 * 16) * 64, wv = wbase + (5 * 16) * 64;
-    wptr c1p = wbase + (6 * 16) * 64, c2p = wbase + (7 * 16) * 64, c3p = wbase + (8 * 16) * 64;
-    wptr cv1p = wbase + (9 * 16) * 64, cv2p = wbase + (10 * 16) * 64;
-    const float bv = wlds[11 * 16 * 64];
+    lds_f4 wl = (lds_f4)(__attribute__((address_space(3))) float *)wlds;
     const int D = P.d_in, A = P.n_act;
     const long long n_tiles = (P.n + kTile - 1) / kTile;
     const long long wave = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -91,182 +58,127 @@ __global__ __launch_bounds__(512) void k_policy_mlp(PolicyArgs P, const float *_
             const float v = obs[env_c * D + (k_in < D ? k_in : 0)];
             x[s] = k_in < D ? v : 0.0f;
         }
-        // critic
-        f32x16 vc;
+        uint32_t legal = 0; // bit r: the action of accumulator register r exists and may be taken
 #pragma unroll
-        for (int r = 0; r < 16; ++r) vc[r] = cv1p[r * 64];
-#pragma unroll
-        for (int s = 0; s < 16; ++s) vc = __builtin_amdgcn_mfma_f32_32x32x2f32(v1[s * 64], x[s], vc, 0, 0, 0);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) vc[r] = fast_tanh(vc[r]);
-        f32x16 vc2;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) vc2[r] = cv2p[r * 64];
-#pragma unroll
-        for (int s = 0; s < 16; ++s) vc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(v2[s * 64], vc[s], vc2, 0, 0, 0);
-        float val = 0.0f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) val = fmaf(fast_tanh(vc2[r]), wv[r * 64], val);
-        val += xhalf(val);
-        val += bv;
-
-        __builtin_amdgcn_sched_barrier(0); // critic first and finished (one scalar left), then the actor: fewer live registers
-        // actor
-        f32x16 acc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = c1p[r * 64];
-#pragma unroll
-        for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s * 64], x[s], acc, 0, 0, 0);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = fast_tanh(acc[r]);
-        f32x16 acc2;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc2[r] = c2p[r * 64];
-#pragma unroll
-        for (int s = 0; s < 16; ++s) acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[s * 64], acc[s], acc2, 0, 0, 0);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc2[r] = fast_tanh(acc2[r]);
-        f32x16 lg;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) lg[r] = c3p[r * 64];
-#pragma unroll
-        for (int s = 0; s < 16; ++s) lg = __builtin_amdgcn_mfma_f32_32x32x2f32(a3[s * 64], acc2[s], lg, 0, 0, 0);
-        // masked logits: this lane owns actions row_of(r, h) < A of env j.  Everything below is selects, no branches:
-        // a per-register `if` turns into an exec-mask region each, and sixteen of them cost more than the MFMAs.
-        float m = -3.0e38f;
-        uint32_t allowed = 0xFFFFu; // bit r: the action in register r may be taken
-        if (mask != nullptr) {      // wave-uniform
-            allowed = 0;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int a = row_of(r, h);
-                allowed |= (mask[env_c * A + (a < A ? a : 0)] != 0 ? 1u : 0u) << r;
-            }
+        for (int r = 0; r < NR; ++r) {
+            const int a = row_of(r, h);
+            const bool ok = a < A && (mask == nullptr || mask[env_c * A + (a < A ? a : 0)] != 0);
+            legal |= (ok ? 1u : 0u) << r;
         }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const bool own = row_of(r, h) < A;
-            lg[r] = own ? (((allowed >> r) & 1u) ? lg[r] : -1.0e8f) : -3.0e38f; // sb3_contrib: HUGE_NEG = -1e8
-            m = fmaxf(m, lg[r]);
-        }
+        const uint32_t word = mse_policy_word(mse_policy_key(P.seed, (uint64_t)(P.index_offset + env)), P.t);
+        float lgm[NR];
+        const TileOut o = policy_tile<NR, F16X3>(wl, lane, x, legal, P.deterministic != 0, word, lgm);
         if (logits_out != nullptr) { // wave-uniform
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                if (row_of(r, h) < A && valid) logits_out[env * A + row_of(r, h)] = lg[r];
+            for (int r = 0; r < NR; ++r)
+                if (row_of(r, h) < A && valid) logits_out[env * A + row_of(r, h)] = lgm[r];
         }
-        m = fmaxf(m, xhalf(m));
-        float e[16], gsum[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            gsum[q] = 0.0f;
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const int r = 4 * q + b;
-                // exp(x) = 2^(x log2 e); x <= 0 here; masked (-1e8 - m) and not-owned entries underflow to exactly 0
-                e[r] = __builtin_amdgcn_exp2f((lg[r] - m) * 1.44269504088896340736f);
-                gsum[q] += e[r];
-            }
-        }
-        // groups of four actions alternate between the halves: group g = 2 q + h holds actions 4 g .. 4 g + 3
-        float other[4], total = 0.0f;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            other[q] = xhalf(gsum[q]);
-            total += h == 0 ? gsum[q] + other[q] : other[q] + gsum[q]; // the same association in both halves
-        }
-        int act = 99;
-        if (P.deterministic) { // wave-uniform
-            float best = -3.0e38f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { // rows ascend with r inside a lane: strict > keeps the lowest index
-                const bool better = lg[r] > best;
-                act = better ? row_of(r, h) : act;
-                best = better ? lg[r] : best;
-            }
-            const float ob = xhalf(best);
-            const int oa = xhalf_i(act);
-            const bool take = ob > best || (ob == best && oa < act);
-            act = take ? oa : act;
-        } else {
-            const uint32_t word = mse_policy_word(mse_policy_key(P.seed, (uint64_t)(P.index_offset + env)), P.t);
-            const float target = (float)(word >> 8) * 5.9604644775390625e-8f * total; // u in [0, 1) times the mass
-            float cum = 0.0f; // inclusive cumulative mass in action order, walked group by group
-            int last = -1;    // the last action of this lane with any mass (fallback when target rounds up to the total)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float g0 = h == 0 ? gsum[q] : other[q], g1 = h == 0 ? other[q] : gsum[q];
-                float c = cum + (h == 0 ? 0.0f : g0); // mass before this lane's group 2 q + h
-#pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    const int r = 4 * q + b;
-                    c += e[r];
-                    const bool has = e[r] > 0.0f;
-                    const bool hit = has && c > target && act == 99;
-                    act = hit ? row_of(r, h) : act;
-                    last = has ? row_of(r, h) : last;
-                }
-                cum += g0 + g1;
-            }
-            const int oa = xhalf_i(act), ol = xhalf_i(last);
-            act = oa < act ? oa : act;
-            last = ol > last ? ol : last;
-            act = act == 99 ? last : act;
-        }
-        // log-probability of the chosen action
-        float la = -3.0e38f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-            if (row_of(r, h) == act) la = lg[r];
-        la = fmaxf(la, xhalf(la));
         if (valid && h == 0) {
-            if (action_out != nullptr) action_out[env] = act;
-            if (logp_out != nullptr) logp_out[env] = la - m - __logf(total);
-            if (value_out != nullptr) value_out[env] = val;
+            if (action_out != nullptr) action_out[env] = o.action;
+            if (logp_out != nullptr) logp_out[env] = o.logp;
+            if (value_out != nullptr) value_out[env] = o.value;
         }
     }
 }
 
-// torch.nn.Linear tensors (include/mse.h order) -> [array][register s][lane] in the order the kernel's registers
-// want them: lane = (half h, row j); layer 1 sums over observation entries k = 2 s + h, the later layers over the
-// previous accumulator's rows k = row_of(s, h); bias register s of a lane belongs to output row row_of(s, h).
-inline int host_row_of(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
-
-std::vector<float> pack_weights(const float *w, int D, int A)
+// torch.nn.Linear tensors (include/mse.h order) -> the image of mse_policy_device.h: A operands in the k order the
+// accumulator registers impose, biases in register order, tanh folded into the weights.  Folding in double:
+//   hidden unit:  r = 1 / (2^z + 1)  with  z = c (W in + b),  c = 2 log2 e,  tanh = 1 - 2 r
+//   a layer fed by r instead of tanh:  W tanh + b = (b + W 1) + (-2 W) r
+std::vector<float> pack_weights(const float *w, int D, int A, bool &f16_ok)
 {
     const int H = kHidden;
     const float *pi_w1 = w, *pi_b1 = pi_w1 + H * D, *pi_w2 = pi_b1 + H, *pi_b2 = pi_w2 + H * H;
     const float *act_w = pi_b2 + H, *act_b = act_w + A * H;
     const float *vf_w1 = act_b + A, *vf_b1 = vf_w1 + H * D, *vf_w2 = vf_b1 + H, *vf_b2 = vf_w2 + H * H;
     const float *val_w = vf_b2 + H, *val_b = val_w + H;
-    std::vector<float> out(kPackedFloats, 0.0f);
-    for (int s = 0; s < 16; ++s) {
-        for (int lane = 0; lane < 64; ++lane) {
-            const int h = lane >> 5, j = lane & 31, k_in = 2 * s + h, k_hid = host_row_of(s, h), row = host_row_of(s, h);
-            auto at = [&](int arr) -> float & { return out[(size_t)(arr * 16 + s) * 64 + lane]; };
-            at(0) = k_in < D ? pi_w1[j * D + k_in] : 0.0f;
-            at(1) = pi_w2[j * H + k_hid];
-            at(2) = j < A ? act_w[j * H + k_hid] : 0.0f;
-            at(3) = k_in < D ? vf_w1[j * D + k_in] : 0.0f;
-            at(4) = vf_w2[j * H + k_hid];
-            at(5) = val_w[k_hid];
-            at(6) = pi_b1[row];
-            at(7) = pi_b2[row];
-            at(8) = row < A ? act_b[row] : 0.0f;
-            at(9) = vf_b1[row];
-            at(10) = vf_b2[row];
+    const double c = 2.0 * 1.4426950408889634073599246810019;
+    // folded dense forms: Wd[L][out][in] (32 x 32, zero padded), bd[L][out]
+    std::vector<double> Wd(5 * 32 * 32, 0.0), bd(5 * 32, 0.0);
+    auto W = [&](int L, int o, int i) -> double & { return Wd[(size_t)(L * 32 + o) * 32 + i]; };
+    auto B = [&](int L, int o) -> double & { return bd[(size_t)L * 32 + o]; };
+    for (int o = 0; o < H; ++o) {
+        for (int i = 0; i < D; ++i) {
+            W(0, o, i) = c * (double)pi_w1[o * D + i];
+            W(3, o, i) = c * (double)vf_w1[o * D + i];
         }
+        B(0, o) = c * (double)pi_b1[o];
+        B(3, o) = c * (double)vf_b1[o];
+        double s1 = 0.0, s4 = 0.0;
+        for (int i = 0; i < H; ++i) {
+            W(1, o, i) = -2.0 * c * (double)pi_w2[o * H + i];
+            W(4, o, i) = -2.0 * c * (double)vf_w2[o * H + i];
+            s1 += (double)pi_w2[o * H + i];
+            s4 += (double)vf_w2[o * H + i];
+        }
+        B(1, o) = c * ((double)pi_b2[o] + s1);
+        B(4, o) = c * ((double)vf_b2[o] + s4);
     }
-    out[11 * 16 * 64] = val_b[0];
+    for (int o = 0; o < A; ++o) {
+        double s2 = 0.0;
+        for (int i = 0; i < H; ++i) {
+            W(2, o, i) = -2.0 * (double)act_w[o * H + i];
+            s2 += (double)act_w[o * H + i];
+        }
+        B(2, o) = (double)act_b[o] + s2;
+    }
+    std::vector<float> out(kBlobFloats, 0.0f);
+    f16_ok = true;
+    uint16_t *h16 = reinterpret_cast<uint16_t *>(out.data() + kOffW16); // [hi | lo][layer][chunk][lane][8]
+    auto f32_of_half = [](uint16_t hb) -> float {
+        const uint32_t sgn = (uint32_t)(hb & 0x8000u) << 16, ex = (hb >> 10) & 0x1Fu, man = hb & 0x3FFu;
+        if (ex == 0) return (sgn ? -1.0f : 1.0f) * std::ldexp((float)man, -24);
+        uint32_t u = sgn | ((ex + 112u) << 23) | (man << 13);
+        float f;
+        std::memcpy(&f, &u, 4);
+        return f;
+    };
+    auto half_rtz = [](float v) -> uint16_t { // f32 -> f16, round toward zero, subnormals kept, |v| < 65520
+        uint32_t u;
+        std::memcpy(&u, &v, 4);
+        const uint16_t sgn = (uint16_t)((u >> 16) & 0x8000u);
+        const int ex = (int)((u >> 23) & 0xFFu) - 127;
+        const uint32_t man = (u & 0x7FFFFFu) | 0x800000u;
+        if (((u >> 23) & 0xFFu) == 0) return sgn;                        // f32 zero / subnormal
+        if (ex >= -14) return (uint16_t)(sgn | ((uint32_t)(ex + 15) << 10) | ((man >> 13) & 0x3FFu));
+        if (ex < -25) return sgn;
+        return (uint16_t)(sgn | (man >> (13 + (-14 - ex))));             // subnormal: shift the mantissa out
+    };
+    auto half_rne = [&](float v) -> uint16_t { // to nearest: the truncated value or its successor, whichever is closer
+        const uint16_t lo_b = half_rtz(v);
+        const uint16_t hi_b = (uint16_t)(lo_b + 1); // next magnitude (same sign); fine below the largest finite half
+        const float a = f32_of_half(lo_b), b = f32_of_half(hi_b);
+        const float da = std::fabs(v - a), db = std::fabs(b - v);
+        return (db < da || (db == da && (hi_b & 1u) == 0)) ? hi_b : lo_b;
+    };
+    for (int L = 0; L < 5; ++L) {
+        const bool input_layer = L == 0 || L == 3;
+        for (int s = 0; s < 16; ++s) {
+            for (int lane = 0; lane < 64; ++lane) {
+                const int hp = lane >> 5, i = lane & 31;
+                const int k = input_layer ? 2 * s + hp : row_of(s, hp); // what this k-step's B operand holds in half hp
+                const float wf = (float)W(L, i, k);
+                out[(size_t)kOffW + ((size_t)(L * 4 + (s >> 2)) * 64 + lane) * 4 + (s & 3)] = wf;
+                if (!(std::fabs(wf) < 65504.0f)) f16_ok = false;
+                const uint16_t hb = f16_ok ? half_rtz(wf) : 0;
+                const uint16_t lb = f16_ok ? half_rne(wf - f32_of_half(hb)) : 0;
+                const size_t at = ((size_t)(L * 2 + (s >> 3)) * 64 + lane) * 8 + (s & 7);
+                h16[at] = hb;
+                h16[(size_t)5 * 2 * 64 * 8 + at] = lb;
+            }
+        }
+        for (int hh = 0; hh < 2; ++hh)
+            for (int r = 0; r < 16; ++r) out[(size_t)kOffB + (L * 2 + hh) * 16 + r] = (float)B(L, row_of(r, hh));
+    }
+    double sv = 0.0;
+    for (int i = 0; i < H; ++i) sv += (double)val_w[i];
+    for (int hh = 0; hh < 2; ++hh)
+        for (int r = 0; r < 16; ++r) out[(size_t)kOffWV + hh * 16 + r] = (float)(-2.0 * (double)val_w[row_of(r, hh)]);
+    out[kOffBV] = (float)((double)val_b[0] + sv);
     return out;
 }
 
 } // namespace
-
-struct mse_policy {
-    int d_in, n_act, device;
-    float *blob;
-    size_t blob_floats;
-};
 
 extern "C" {
 
@@ -285,8 +197,9 @@ int mse_policy_create(mse_policy **out, int obs_dim, int n_actions, const float 
     if (hipGetDeviceCount(&count) != hipSuccess || count == 0 || device_id < 0 || device_id >= count)
         return mse_internal_fail(MSE_ERR_NO_DEVICE, "mse_policy_create: no such HIP device");
     if (hipSetDevice(device_id) != hipSuccess) return mse_internal_fail(MSE_ERR_HIP, "hipSetDevice failed");
-    const std::vector<float> packed = pack_weights(weights_host, obs_dim, n_actions);
-    mse_policy *p = new mse_policy{obs_dim, n_actions, device_id, nullptr, packed.size()};
+    bool f16_ok = false;
+    const std::vector<float> packed = pack_weights(weights_host, obs_dim, n_actions, f16_ok);
+    mse_policy *p = new mse_policy{obs_dim, n_actions, device_id, nullptr, packed.size(), f16_ok ? 1 : 0, 0};
     if (hipMalloc(reinterpret_cast<void **>(&p->blob), p->blob_floats * sizeof(float)) != hipSuccess ||
         hipMemcpy(p->blob, packed.data(), p->blob_floats * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
         if (p->blob) (void)hipFree(p->blob);
@@ -296,6 +209,17 @@ int mse_policy_create(mse_policy **out, int obs_dim, int n_actions, const float 
     *out = p;
     return MSE_OK;
 }
+
+int mse_policy_set_precision(mse_policy *p, int mode)
+{
+    if (p == nullptr || mode < 0 || mode > 2) return mse_internal_fail(MSE_ERR_INVALID_ARGUMENT, "mse_policy_set_precision: bad argument");
+    if (mode == 2 && !p->f16_ok)
+        return mse_internal_fail(MSE_ERR_UNSUPPORTED_CONFIG, "mse_policy_set_precision: a folded weight exceeds f16's range (65 504)");
+    p->precision = mode;
+    return MSE_OK;
+}
+
+int mse_policy_precision(const mse_policy *p) { return p == nullptr ? -1 : (p->use_f16() ? 2 : 1); }
 
 int mse_policy_destroy(mse_policy *p)
 {
@@ -314,10 +238,24 @@ int mse_policy_forward(mse_policy *p, int64_t n, int64_t index_offset, const flo
     PolicyArgs a{(long long)n, (long long)index_offset, p->d_in, p->n_act, deterministic ? 1 : 0, seed, t};
     const long long tiles = (n + kTile - 1) / kTile;
     long long blocks = (tiles + 7) / 8; // 8 waves per block = two per SIMD
-    if (blocks > 256) blocks = 256;     // one workgroup per CU, then grid-stride over the tiles
-    hipLaunchKernelGGL(k_policy_mlp, dim3((unsigned)blocks), dim3(512), kPackedFloats * sizeof(float),
-                       static_cast<hipStream_t>(stream), a, p->blob,
-                       obs_dev, mask_dev, action_out, logp_out, value_out, logits_out);
+    if (blocks > 512) blocks = 512;     // two workgroups per CU (21 KB of LDS each), then grid-stride over the tiles
+    const int nr = regs_for_actions(p->n_act); // accumulator registers that can hold an action: 2 .. 16
+#define MSE_LAUNCH_POLICY(NR, F16)                                                                                   \
+    hipLaunchKernelGGL((k_policy_mlp<NR, F16>), dim3((unsigned)blocks), dim3(512), kLdsFloats * sizeof(float),       \
+                       static_cast<hipStream_t>(stream), a, p->blob, obs_dev, mask_dev, action_out, logp_out,        \
+                       value_out, logits_out)
+    if (p->use_f16()) {
+        if (nr <= 2) MSE_LAUNCH_POLICY(2, true);
+        else if (nr <= 7) MSE_LAUNCH_POLICY(7, true);
+        else if (nr <= 12) MSE_LAUNCH_POLICY(12, true);
+        else MSE_LAUNCH_POLICY(16, true);
+    } else {
+        if (nr <= 2) MSE_LAUNCH_POLICY(2, false);
+        else if (nr <= 7) MSE_LAUNCH_POLICY(7, false);
+        else if (nr <= 12) MSE_LAUNCH_POLICY(12, false);
+        else MSE_LAUNCH_POLICY(16, false);
+    }
+#undef MSE_LAUNCH_POLICY
     if (hipGetLastError() != hipSuccess) return mse_internal_fail(MSE_ERR_HIP, "mse_policy_forward: kernel launch failed");
     return MSE_OK;
 }

@@ -38,8 +38,10 @@ def _shapes(obs_dim: int, n_actions: int):
 class MlpPolicy:
     """weights: mapping from the SB3 state_dict names (SB3_KEYS) to arrays / tensors of the documented shapes."""
 
+    PRECISIONS = {"auto": 0, "f32": 1, "f16x3": 2}
+
     def __init__(self, obs_dim: int, n_actions: int, weights: Mapping[str, object], device: int | str | torch.device = 0,
-                 library: Optional[str] = None):
+                 library: Optional[str] = None, precision: str = "auto"):
         if not torch.cuda.is_available():
             raise RuntimeError("MlpPolicy needs a HIP device: there is no CPU fallback")
         self.L = load_library(library)
@@ -62,6 +64,15 @@ class MlpPolicy:
         check(self.L.mse_policy_create(C.byref(h), self.obs_dim, self.n_actions,
                                        blob.ctypes.data_as(C.POINTER(C.c_float)), dev_index))
         self._h = h
+        self.set_precision(precision)
+
+    def set_precision(self, precision: str) -> str:
+        """"f32": exact f32 matrix products; "f16x3": three f16 MFMAs per product on 22-bit operand splits (logits
+        within ~1e-6 of f32, 5x the matrix rate); "auto": f16x3 when the weights fit f16's range.  Returns the form
+        in effect."""
+        check(self.L.mse_policy_set_precision(self._h, self.PRECISIONS[precision]))
+        self.precision = "f16x3" if self.L.mse_policy_precision(self._h) == 2 else "f32"
+        return self.precision
 
     @classmethod
     def from_state_dict(cls, state_dict: Mapping[str, object], device=0, library: Optional[str] = None) -> "MlpPolicy":
@@ -69,6 +80,21 @@ class MlpPolicy:
         w1 = state_dict["mlp_extractor.policy_net.0.weight"]
         wa = state_dict["action_net.weight"]
         return cls(int(w1.shape[1]), int(wa.shape[0]), state_dict, device=device, library=library)
+
+    @classmethod
+    def random_init(cls, obs_dim: int, n_actions: int, seed: int = 0, device=0, library: Optional[str] = None,
+                    precision: str = "auto") -> "MlpPolicy":
+        """Random weights of the reference's architecture in SB3's initial scale (orthogonal-like magnitudes: hidden
+        layers ~ sqrt(2) / sqrt(fan_in), action head 0.01, value head 1) - for benchmarks and smoke runs."""
+        rng = np.random.default_rng(seed)
+        w = {}
+        for key, shape in zip(SB3_KEYS, _shapes(obs_dim, n_actions)):
+            if len(shape) == 1:
+                w[key] = np.zeros(shape, dtype=np.float32)
+            else:
+                gain = 0.01 if key == "action_net.weight" else (1.0 if key == "value_net.weight" else np.sqrt(2.0))
+                w[key] = (rng.standard_normal(shape) * gain / np.sqrt(shape[1])).astype(np.float32)
+        return cls(obs_dim, n_actions, w, device=device, library=library, precision=precision)
 
     def close(self):
         if getattr(self, "_h", None):

@@ -61,14 +61,16 @@ def _word(seed, g, t):
     return _fmix32(c ^ key)
 
 
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
 @pytest.mark.parametrize("obs_dim,n_actions,n", [(29, 22, 1000), (16, 11, 333), (13, 2, 64), (29, 22, 31)])
-def test_policy_forward_matches_torch_fp32(obs_dim, n_actions, n):
+def test_policy_forward_matches_torch_fp32(obs_dim, n_actions, n, precision):
     import torch
 
     import marl_sortingenv_amd as M
 
     w = _weights(obs_dim, n_actions, seed=obs_dim * 100 + n_actions)
-    pol = M.MlpPolicy(obs_dim, n_actions, w, device=0)
+    pol = M.MlpPolicy(obs_dim, n_actions, w, device=0, precision=precision)
+    assert pol.precision == precision
     g = torch.Generator().manual_seed(5)
     obs = torch.rand((n, obs_dim), generator=g)  # observations live in [0, 1] (clip in env_super.py:339-359)
     mask = torch.rand((n, n_actions), generator=g) < 0.6
@@ -86,14 +88,17 @@ def test_policy_forward_matches_torch_fp32(obs_dim, n_actions, n):
             assert bool(mk.gather(1, act.unsqueeze(1)).all()), "a masked action was sampled"
         # log-probability of the sampled action
         assert torch.allclose(out["logp"].cpu(), ref_logsm.gather(1, act.unsqueeze(1)).squeeze(1), atol=LOGP_TOL)
-        # the sample is the inverse cdf of the engine's stream in action order: recompute it in fp64 from the
-        # device's own logits; a draw that lands within 1e-5 of a boundary may fall on either side
-        p = torch.softmax(logits.double(), dim=1).numpy()
+        # the sample is the inverse cdf of the engine's stream over the softmax masses in REGISTER order (the MFMA
+        # accumulator's rows of half 0, then half 1: csrc/mse_policy_device.h): recompute it in fp64 from the device's
+        # own logits; a draw that lands within 1e-5 of a boundary may fall on either side
+        order = [a for h in (0, 1) for r in range(16) for a in [(r & 3) + 8 * (r >> 2) + 4 * h] if a < n_actions]
+        assert sorted(order) == list(range(n_actions))
+        p = torch.softmax(logits.double(), dim=1).numpy()[:, order]
         cdf = np.cumsum(p, axis=1)
         for i in range(n):
             u = (_word(77, i, 3) >> 8) * 2.0 ** -24
             k = int(np.searchsorted(cdf[i], u, side="right"))
-            k = min(k, n_actions - 1)
+            k = order[min(k, n_actions - 1)]
             if int(act[i]) != k:
                 near = min(abs(u - cdf[i, j]) for j in range(n_actions))
                 assert near < 1e-5, (i, int(act[i]), k, u, cdf[i])
@@ -185,3 +190,62 @@ def test_collector_fills_rollout_buffers_consistently(kind):
         assert torch.equal(rew, out["rewards"][k])
     assert torch.equal(out["last_dones"], twin.done)
     assert env.error_count() == 0
+
+
+def test_f16x3_form_tracks_the_exact_f32_form():
+    """The split form (three f16 MFMAs per product on 22-bit operand pairs) against the exact f32 form of the same
+    kernel: logits (magnitudes up to ~6 here) and values within 1.2e-5 - measured 6.7e-6, of which ~2e-6 is the f32
+    form's own summation-order noise - inside the 2e-5 the parity test allows either form against PyTorch; a policy
+    whose folded weights exceed f16's range falls back to f32 by itself."""
+    import torch
+
+    import marl_sortingenv_amd as M
+
+    w = _weights(29, 22, seed=77)
+    obs = torch.rand((4096, 29), generator=torch.Generator().manual_seed(3)).cuda()
+    exact = M.MlpPolicy(29, 22, w, device=0, precision="f32").forward(obs, None, want_logits=True, deterministic=True)
+    split = M.MlpPolicy(29, 22, w, device=0, precision="f16x3").forward(obs, None, want_logits=True, deterministic=True)
+    assert float((exact["logits"] - split["logits"]).abs().max()) < 1.2e-5
+    assert float((exact["value"] - split["value"]).abs().max()) < 1.2e-5
+    big = dict(w)
+    big["mlp_extractor.policy_net.2.weight"] = w["mlp_extractor.policy_net.2.weight"] * 3.0e4
+    pol = M.MlpPolicy(29, 22, big, device=0)
+    assert pol.precision == "f32"
+    with pytest.raises(M.MseError):
+        pol.set_precision("f16x3")
+    assert M.MlpPolicy(29, 22, w, device=0).precision == "f16x3"  # auto
+
+
+@pytest.mark.parametrize("precision", ["f16x3", "f32"])
+@pytest.mark.parametrize("kind,noise,n,K", [("mono", 0.0, 5000, 24), ("mono", 0.05, 777, 23), ("press", 0.05, 1030, 21),
+                                            ("sort", 0.0, 600, 25), ("mono", 0.0, 70300, 6)])
+def test_fused_policy_rollout_equals_two_launch_collector(kind, noise, n, K, precision):
+    """mse_rollout_policy (policy forward inside the rollout kernel, one launch per rollout) fills the same
+    MaskableRolloutBuffer-shaped tensors, bit for bit, as alternating mse_policy_forward and mse_step; the env state
+    afterwards is the same too, over several consecutive rollouts (ragged N, auto-resets inside a rollout)."""
+    import torch
+
+    import marl_sortingenv_amd as M
+
+    kw = dict(kind=kind, num_envs=n, device=0, base_seed=17, max_steps=10, noise_sorting=noise, balesize=200)
+    a, b = M.BatchedSortingEnv(**kw), M.BatchedSortingEnv(**kw)
+    pol = M.MlpPolicy(a.obs_dim, a.num_actions, _weights(a.obs_dim, a.num_actions, seed=31), device=0, precision=precision)
+    sm = (torch.arange(n) % 2).to(torch.int32).cuda() if kind == "press" else None
+    two = M.PolicyRolloutCollector(a, pol, K, seed=5)
+    if sm is not None:  # the two-launch collector takes Env_2's sorting decisions from a policy; feed it the tensor
+        class Frozen:
+            def forward(self, *args, **kwargs):
+                return {"action": sm}
+        two.sort_policy = Frozen()
+    fused = M.FusedPolicyRollout(b, pol, K, seed=5, sort_mode=sm)
+    for it in range(3):
+        x, y = two.collect(), fused.collect()
+        for key in ("observations", "action_masks", "episode_starts", "actions", "log_probs", "values", "rewards",
+                    "last_values", "last_dones"):
+            assert torch.equal(x[key], y[key]), (it, key)
+        for sa, sb in zip(a.get_state(), b.get_state()):
+            assert torch.equal(sa, sb), it
+    assert a.policy_step == b.policy_step == 3 * K and b.error_count() == 0
+    # deterministic (argmax) collection agrees as well
+    x, y = two.collect(deterministic=True), fused.collect(deterministic=True)
+    assert torch.equal(x["actions"], y["actions"]) and torch.equal(x["rewards"], y["rewards"])

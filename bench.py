@@ -34,9 +34,10 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
-# SQ_ACTIVE_INST_VALU / (SQ_WAVE_CYCLES / 3 waves per SIMD) of k_rollout_ring, profiles/r01/v6_summary.json (re-measured
-# per round in profiles/rNN/): the share of cycles in which a SIMD's VALU is issuing
-VALU_ISSUE_RATIO = 0.77
+# SQ_ACTIVE_INST_VALU / (SQ_WAVE_CYCLES / waves per SIMD), profiles/r02/summary.json (tags sq_k64, sq_mlp_262144): the
+# share of cycles in which a SIMD's VALU is issuing - k_rollout_ring 0.83 (3 waves per SIMD), k_rollout_policy 0.87 (2)
+VALU_ISSUE_RATIO = {"random": 0.83, "mlp": 0.87}
+F16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense f16 / bf16 matrix peak
 
 
 def cpu_baseline(kind: str, max_steps: int, noise: float, balesize: int, budget_s: float = 12.0):
@@ -292,9 +293,20 @@ def main():
                 # bytes, so this figure can pass 1.0 on long launches of large batches - kept for comparison only
                 "contract_bytes_per_env_step": bytes_contract, "achieved_contract": achieved_contract,
                 "frac_contract": None if achieved_contract is None else achieved_contract / HBM_PEAK_GBPS,
-                "valu_issue_ratio": VALU_ISSUE_RATIO,
+                "valu_issue_ratio": VALU_ISSUE_RATIO[args.policy],
             },
         }
+        if collector is not None and per_launch_ms:
+            # the policy network's share: 10 240 flop per env and forward (5 layers of 32 x 32 x 2), one forward per
+            # step plus the bootstrap forward per launch; in the f16x3 form each product costs three f16 MFMAs
+            fwd = n * (steps_per_launch_avg + 1)
+            f32_equiv = 10240.0 * fwd / (per_launch_ms * 1e-3) / 1e12
+            split = collector.policy.precision == "f16x3"
+            out["roofline"]["mfma"] = {
+                "form": collector.policy.precision, "f32_equivalent_tflops": f32_equiv,
+                "achieved": f32_equiv * (3.0 if split else 1.0), "peak": F16_MFMA_PEAK_TFLOPS if split else 157.3,
+                "unit": "TFLOP/s", "frac": f32_equiv * (3.0 if split else 1.0) / (F16_MFMA_PEAK_TFLOPS if split else 157.3),
+            }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.kind, args.max_steps, args.noise, 200, args.cpu_budget)
         print(json.dumps(out), flush=True)

@@ -69,7 +69,9 @@ typedef struct mse_config {
     int32_t  literal_choice;       /* 1: always evaluate Generator.choice(4,p) in literal fp64 (test switch);
                                       0: exact integer decision with literal fallback near ties */
     /* simulation (config.yml:4-9) */
-    int32_t  input_batch_size;     /* <= 255, must leave no floor() remainder for both patterns */
+    int32_t  input_batch_size;     /* <= 255.  If floor(ratio * batch) leaves units over (e.g. 90), the generator's
+                                      random remainder + shuffle draws run on the device ("general generator mode",
+                                      utils/input_generator.py:46-61) and the one-lane kernels serve the handle */
     int32_t  steps_per_pattern;    /* informational: reset() rebuilds the generator with its default 20
                                       (env_super.py:375), so 20 is what every episode uses */
     /* sorting_station (config.yml:12-18) */
@@ -193,11 +195,13 @@ int mse_rule_actions(mse_env *env, int32_t *action_out, void *stream);
 /* State export / import in a fixed record layout (tests, checkpoint/resume, dashboard trace):
  *   ints  i64[N, MSE_SNAP_INTS]  (column map: MSE_SNAP_* below)
  *   dbls  f64[N, 4]              accuracy_belt
- *   rng   u64[N, 24]             {state_hi,state_lo,inc_hi,inc_lo,has_uint32,uinteger} x
- *                                {rng (seed+99), rng_noise (seed+4), rng_pressing (seed+3), rng_sorting (seed+2)}
+ *   rng   u64[N, 30]             {state_hi,state_lo,inc_hi,inc_lo,has_uint32,uinteger} x
+ *                                {rng (seed+99), rng_noise (seed+4), rng_pressing (seed+3), rng_sorting (seed+2),
+ *                                 the input generator's private default_rng(seed) (utils/input_generator.py:28; it only
+ *                                 advances in general generator mode, i.e. when floor(ratio * batch) leaves units over)}
  * Replaces reading/writing the attributes of Env_Super (env_super.py:52-137). */
 #define MSE_SNAP_INTS 71
-#define MSE_SNAP_RNG_WORDS 24
+#define MSE_SNAP_RNG_WORDS 30
 int mse_get_state(mse_env *env, int64_t *ints_out, double *dbls_out, uint64_t *rng_out, void *stream);
 int mse_set_state(mse_env *env, const int64_t *ints_in, const double *dbls_in, const uint64_t *rng_in, void *stream);
 

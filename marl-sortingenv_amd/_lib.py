@@ -10,7 +10,7 @@ MSE_ENV_SORT, MSE_ENV_PRESS, MSE_ENV_MONO = 1, 2, 3
 MSE_STEP_UNMASKED, MSE_STEP_CHECK_OVERFLOW, MSE_ROLLOUT_RULE_BASED, MSE_STEP_SANITIZE_LATE = 1, 2, 4, 8
 MSE_MODEL_NO_SORT_DRAW, MSE_MODEL_NO_PRESS_DRAW = 16, 32
 MSE_SNAP_INTS = 71
-MSE_SNAP_RNG_WORDS = 24  # rng, rng_noise, rng_pressing, rng_sorting x {state_hi, state_lo, inc_hi, inc_lo, has_uint32, uinteger}
+MSE_SNAP_RNG_WORDS = 30  # rng, rng_noise, rng_pressing, rng_sorting, input generator x {state_hi, state_lo, inc_hi, inc_lo, has_uint32, uinteger}
 MSE_TRACE_COLS = 40
 
 EXPORTS = [

@@ -46,6 +46,9 @@ enum Plane : int {
     PL_SORTRNG_STATE,  // rng_sorting (seed+2): only Env_3's mode='model' fallback draws from it (k_model_actions); cold
     PL_SORTRNG_INC,
     PL_SORTRNG_AUX,    // {uinteger, has_uint32, 0, 0} of rng_sorting's 32-bit buffer
+    PL_GEN_STATE,      // the SeasonalInputGenerator's private default_rng(seed) (utils/input_generator.py:28): only a batch
+    PL_GEN_INC,        // size whose floor() leaves a remainder makes its draws observable (Params::gen_mode); cold otherwise
+    PL_GEN_AUX,        // {uinteger, has_uint32, 0, 0}
     PL_COUNT
 };
 
@@ -86,6 +89,13 @@ struct Params {
     uint32_t qi_down[4]; // bit q set: int((q / 100.0) * 100.0) == q - 1  (press_bale's stored quality)
     int rem_thr_units;   // floor(bale_standard_size * bale_remainder_threshold)
     int ring_worst; // most sort_material draws one step can make with this config (k_rollout_ring flow control)
+    // General generator mode (utils/input_generator.py:46-61 with a floor() remainder, e.g. input_batch_size 90): the stage
+    // vectors are carried as their packed counts instead of pattern ids, the generator's private stream runs on the
+    // device (remainder draws + the shuffle's draws), and only the one-lane kernels serve the handle.
+    int gen_mode;
+    int gen_rem[3];            // units left after the floor()s, per pattern key (index 1 | 2)
+    uint32_t occ_nonempty;     // f32 bits of clip(float(round(batch / 100, 2))): occupancy of a stage that holds a batch
+    int off_gprop, off_gfrac;  // tables by count: clip(float(k / batch)), clip(float(k / stage_capacity)), k = 0..255
     double acc_floor[4]; // lowest accuracy_belt[m] the config can produce: clip(baseline [+ boost] - noise).  ring_worst
                          // is derived from it, so mse_set_state counts anything below as an error (mse_error_count)
 };
@@ -331,10 +341,13 @@ struct Env {
     Pcg press;          // seed+3 : Env_1's internal press sampling
     uint32_t press_uint;
     int press_has;
+    Pcg gen;            // the input generator's private stream (general generator mode only)
+    uint32_t gen_uint;
+    int gen_has;
     double acc[4];      // accuracy_belt
     int ct[4], cf[4], ce;
     int pn[2], lpa;
-    int st_in, st_belt, st_sort; // stage ids: 0 empty, 1 / 2 seasonal pattern
+    int st_in, st_belt, st_sort; // stage ids: 0 empty, 1 / 2 seasonal pattern (general generator mode: the packed counts)
     int timer[2], pmat[2], q100[2];
     int mode, lps, gen2, gen_idx, gen_cnt, step;
     uint32_t episode;
@@ -342,10 +355,12 @@ struct Env {
 
 __device__ __forceinline__ int stage_id(uint32_t word, const Params &P)
 {
+    if (P.gen_mode) return (int)word; // general generator: the register image is the packed counts themselves
     return word == 0u ? 0 : (word == P.pat_word[1] ? 1 : 2);
 }
 __device__ __forceinline__ uint32_t stage_word(int id, const Params &P)
 {
+    if (P.gen_mode) return (uint32_t)id;
     return id == 0 ? P.pat_word[0] : (id == 1 ? P.pat_word[1] : P.pat_word[2]);
 }
 
@@ -549,10 +564,50 @@ __device__ __forceinline__ bool press_action_valid(const Env &e, const Params &P
     return lvl >= P.balesize;
 }
 
-// SeasonalInputGenerator.generate_input reduced to the pattern id (utils/input_generator.py:37-64;
-// with a remainder-free batch the material counts are a function of the pattern alone) followed by
-// env_super.py:433-461 update_environment
-__device__ __forceinline__ void update_environment(Env &e)
+// numpy's Generator draws on 32-bit words: next_uint32 hands out the low half of a PCG64 output and buffers the high
+// half (pcg64.h pcg64_next32); choice(n) / choice(arr) / integers without p are Lemire's bounded draw on it
+// (distributions.c buffered_bounded_lemire_uint32), no draw when n == 1.
+struct Rng32 {
+    Pcg g;
+    uint32_t uinteger;
+    int has;
+    __device__ __forceinline__ uint32_t next32()
+    {
+        if (has) {
+            has = 0;
+            return uinteger;
+        }
+        const uint64_t r = pcg_next64(g);
+        has = 1;
+        uinteger = (uint32_t)(r >> 32);
+        return (uint32_t)r;
+    }
+    __device__ __forceinline__ uint32_t lemire(uint32_t n) // uniform in [0, n), n >= 1
+    {
+        if (n <= 1u) return 0u;
+        uint64_t m = (uint64_t)next32() * n;
+        uint32_t leftover = (uint32_t)m;
+        if (leftover < n) {
+            const uint32_t threshold = (0xFFFFFFFFu - (n - 1u)) % n;
+            while (leftover < threshold) {
+                m = (uint64_t)next32() * n;
+                leftover = (uint32_t)m;
+            }
+        }
+        return (uint32_t)(m >> 32);
+    }
+};
+
+// SeasonalInputGenerator.generate_input (utils/input_generator.py:37-64) followed by env_super.py:433-461
+// update_environment.
+//   GEN = false: with a remainder-free batch the material counts are a function of the pattern alone, the stage
+//                vectors travel as pattern ids and the generator's private stream is never observed.
+//   GEN = true:  floor(ratio * batch) leaves units over; each goes to rng.choice(material_names) (:49-55), and the
+//                batch list is then shuffled (:58-61: Generator.shuffle of a Python list = one random_interval(i) per
+//                i = n-1 .. 1, a masked rejection draw on next_uint32) - the shuffle's result is never read, but its
+//                draws move the stream the next step's remainder choices come from, so they are made here, one by one.
+template <bool GEN>
+__device__ __forceinline__ void update_environment(Env &e, const Params &P)
 {
     e.st_sort = e.st_belt;
     e.st_belt = e.st_in;
@@ -560,7 +615,24 @@ __device__ __forceinline__ void update_environment(Env &e)
         e.gen_idx ^= 1;
         e.gen_cnt = 0;
     }
-    e.st_in = 1 + (e.gen_idx ^ e.gen2);
+    const int key = 1 + (e.gen_idx ^ e.gen2);
+    if (!GEN) {
+        e.st_in = key;
+    } else {
+        Rng32 g{e.gen, e.gen_uint, e.gen_has};
+        uint32_t word = key == 1 ? P.pat_word1 : P.pat_word2; // the floor()ed counts
+        const int rem = key == 1 ? P.gen_rem[1] : P.gen_rem[2];
+        for (int r = 0; r < rem; ++r) word += 1u << (8u * g.lemire(4u));
+        int i = P.batch - 1; // random_interval(i): value = next_uint32() & mask(i) until value <= i
+        while (i > 0) {
+            const uint32_t mask = 0xFFFFFFFFu >> __builtin_clz((unsigned)i);
+            if ((g.next32() & mask) <= (uint32_t)i) --i;
+        }
+        e.gen = g.g;
+        e.gen_uint = g.uinteger;
+        e.gen_has = g.has;
+        e.st_in = (int)word;
+    }
     e.gen_cnt += 1;
 }
 
@@ -1371,6 +1443,8 @@ struct Tables {
     const double *cst;     // [CST_COUNT], see enum Cst
     const uint64_t *jump;  // [kJumpBits][4] LCG jump-ahead (pcg_jump)
     const uint64_t *back;  // [kRingBackSteps][4] LCG jump BACK by d = 0..31 steps (pcg_step_back)
+    const float *gprop;    // [256] general generator mode: clip(float(k / batch))          env_super.py:199-210
+    const float *gfrac;    // [256]                         clip(float(k / stage_capacity)) env_super.py:351
 };
 
 __device__ __forceinline__ Tables tables_at(const uint32_t *base, const Params &P)
@@ -1389,17 +1463,67 @@ __device__ __forceinline__ Tables tables_at(const uint32_t *base, const Params &
     t.cst = reinterpret_cast<const double *>(base + P.off_cst);
     t.jump = reinterpret_cast<const uint64_t *>(base + P.off_jump);
     t.back = reinterpret_cast<const uint64_t *>(base + P.off_back);
+    t.gprop = reinterpret_cast<const float *>(base + P.off_gprop);
+    t.gfrac = reinterpret_cast<const float *>(base + P.off_gfrac);
     return t;
 }
 
 __device__ __forceinline__ float clip_f(float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
+// What a step reads off a stage vector.  GEN = false: the vector is one of three words, carried as its id, and every
+// derived quantity is a per-id record of the table image.  GEN = true: carried as its packed counts (u8 x 4); shares
+// and fractions come from per-count tables (the batch total is constant), sorting_rules() is evaluated literally.
+template <bool GEN>
+struct Stage {
+    static __device__ __forceinline__ uint32_t word(int st, const Params &P)
+    {
+        if (GEN) return (uint32_t)st;
+        const uint32_t pw1 = P.pat_word1, pw2 = P.pat_word2;
+        return st == 1 ? pw1 : (st == 2 ? pw2 : 0u);
+    }
+    static __device__ __forceinline__ float occupancy(int st, const Params &P, const Tables &tb)
+    {
+        if (GEN) return st != 0 ? __uint_as_float(P.occ_nonempty) : 0.0f;
+        return __uint_as_float(tb.pat[st * kPatStride + 1]);
+    }
+    static __device__ __forceinline__ float4 proportions(int st, const Tables &tb) // env_super.py:199-210
+    {
+        if (GEN) {
+            const uint32_t w = (uint32_t)st;
+            if (w == 0u) return make_float4(0.f, 0.f, 0.f, 0.f);
+            return make_float4(tb.gprop[w & 0xFFu], tb.gprop[(w >> 8) & 0xFFu], tb.gprop[(w >> 16) & 0xFFu], tb.gprop[w >> 24]);
+        }
+        return *reinterpret_cast<const float4 *>(tb.pat + st * kPatStride + 4);
+    }
+    static __device__ __forceinline__ float4 fractions(int st, const Tables &tb) // env_super.py:351
+    {
+        if (GEN) {
+            const uint32_t w = (uint32_t)st;
+            return make_float4(tb.gfrac[w & 0xFFu], tb.gfrac[(w >> 8) & 0xFFu], tb.gfrac[(w >> 16) & 0xFFu], tb.gfrac[w >> 24]);
+        }
+        return *reinterpret_cast<const float4 *>(tb.pat + st * kPatStride + 8);
+    }
+    static __device__ __forceinline__ int rule_mode(int st, const Tables &tb) // env_super.py:469-482 sorting_rules()
+    {
+        if (GEN) {
+            const uint32_t w = (uint32_t)st;
+            const int c0 = (int)(w & 0xFFu), c1 = (int)((w >> 8) & 0xFFu), c2 = (int)((w >> 16) & 0xFFu), c3 = (int)(w >> 24);
+            const int total = c0 + c1 + c2 + c3;
+            if (total == 0) return 1;
+            const double t = (double)total;
+            const double p0 = (double)c0 / t, p1 = (double)c1 / t, p2 = (double)c2 / t, p3 = (double)c3 / t;
+            return (p0 + p2 > p1 + p3) ? 0 : 1;
+        }
+        return (int)tb.pat[st * kPatStride + 2];
+    }
+};
+
 // env_super.py:306-325 get_sort_obs -> o[0..12]
-__device__ __forceinline__ void sort_obs(const Env &e, const Tables &tb, const int k[4], float *o)
+template <bool GEN = false>
+__device__ __forceinline__ void sort_obs(const Env &e, const Params &P, const Tables &tb, const int k[4], float *o)
 {
-    const uint32_t *rec = tb.pat + e.st_belt * kPatStride;
-    o[0] = __uint_as_float(rec[1]); // belt_occupancy = the input occupancy of the batch that is now on the belt
-    const float4 prop = *reinterpret_cast<const float4 *>(rec + 4);
+    o[0] = Stage<GEN>::occupancy(e.st_belt, P, tb); // belt_occupancy = the input occupancy of the batch now on the belt
+    const float4 prop = Stage<GEN>::proportions(e.st_belt, tb);
     o[1] = prop.x;
     o[2] = prop.y;
     o[3] = prop.z;
@@ -1411,6 +1535,7 @@ __device__ __forceinline__ void sort_obs(const Env &e, const Tables &tb, const i
 }
 
 // env_super.py:327-359 get_press_obs -> o[0..15]
+template <bool GEN = false>
 __device__ __forceinline__ void press_obs(const Env &e, const Params &P, const Tables &tb, float *o)
 {
 #pragma unroll
@@ -1420,7 +1545,7 @@ __device__ __forceinline__ void press_obs(const Env &e, const Params &P, const T
         o[m] = v;
         o[5 + m] = v;
     }
-    const float4 frac = *reinterpret_cast<const float4 *>(tb.pat + e.st_sort * kPatStride + 8);
+    const float4 frac = Stage<GEN>::fractions(e.st_sort, tb);
     o[10] = frac.x;
     o[11] = frac.y;
     o[12] = frac.z;
@@ -1444,16 +1569,16 @@ struct Dims<3> {
     static constexpr int D = 29, A = 22;
 };
 
-template <int KIND>
+template <int KIND, bool GEN = false>
 __device__ __forceinline__ void env_obs(const Env &e, const Params &P, const Tables &tb, const int k[4], float *o)
 {
     if (KIND == 1) {
-        sort_obs(e, tb, k, o);
+        sort_obs<GEN>(e, P, tb, k, o);
     } else if (KIND == 2) {
-        press_obs(e, P, tb, o);
+        press_obs<GEN>(e, P, tb, o);
     } else {
-        sort_obs(e, tb, k, o);
-        press_obs(e, P, tb, o + 13);
+        sort_obs<GEN>(e, P, tb, k, o);
+        press_obs<GEN>(e, P, tb, o + 13);
     }
 }
 
@@ -1533,7 +1658,7 @@ __device__ __forceinline__ PenaltyClass classify_levels(const int lvl[5], const 
 
 // env_1_sort.py:97-154 / env_2_press.py:88-165 / env_monolith.py:109-284 up to (not including) the reward
 // and observation, plus the state side effects of calculate_press_reward and the step counter.
-template <int KIND, bool NOISE, bool LITERAL, class RNG, bool TRACE = false>
+template <int KIND, bool NOISE, bool LITERAL, class RNG, bool TRACE = false, bool GEN = false>
 __device__ __forceinline__ void env_dynamics(Env &e, RNG &rng, const Params &P, const Tables &tb, int action,
                                              int sort_mode_in, uint32_t flags, const BaleRef &bales, Snap &sn,
                                              Ledger *lg = nullptr)
@@ -1544,9 +1669,8 @@ __device__ __forceinline__ void env_dynamics(Env &e, RNG &rng, const Params &P, 
 
     // input_action_rules draws rng_input.integers(60,81) and discards it (env_super.py:911-922, :433);
     // that stream is never observed, so it is not carried.
-    update_environment(e);
-    const uint32_t pw1 = P.pat_word1, pw2 = P.pat_word2;
-    const uint32_t sorting_word = e.st_sort == 1 ? pw1 : (e.st_sort == 2 ? pw2 : 0u); // current_material_sorting
+    update_environment<GEN>(e, P);
+    const uint32_t sorting_word = Stage<GEN>::word(e.st_sort, P); // current_material_sorting
 
     int sort_mode, press_action = 0;
     bool run_press_rules = true;
@@ -1554,7 +1678,7 @@ __device__ __forceinline__ void env_dynamics(Env &e, RNG &rng, const Params &P, 
         sort_mode = action;
     } else if (KIND == 2) {
         // the sorting agent's decision, else sorting_rules() on the post-flow belt (env_super.py:469-482)
-        sort_mode = sort_mode_in >= 0 ? sort_mode_in : (int)tb.pat[e.st_belt * kPatStride + 2];
+        sort_mode = sort_mode_in >= 0 ? sort_mode_in : Stage<GEN>::rule_mode(e.st_belt, tb);
         press_action = action;
     } else {
         sort_mode = action >= 11 ? 1 : 0;
@@ -1651,7 +1775,7 @@ struct StepResult {
 //
 // Table reads are issued in two batches and consumed behind fp64 divisions: at one wave per SIMD an
 // LDS read that is waited for right after its issue costs the full round trip.
-template <int KIND, bool NOISE>
+template <int KIND, bool NOISE, bool GEN = false>
 __device__ __forceinline__ StepResult env_observe(const Snap &sn, const Params &P, const Tables &tb, int k[4], float *o)
 {
     // ---- batch A: everything that needs only the integer state -----------------------------------
@@ -1666,13 +1790,12 @@ __device__ __forceinline__ StepResult env_observe(const Snap &sn, const Params &
         for (int m = 0; m < 5; ++m) lvl_f[m] = tb.lvl[lvl[m] < P.capacity ? lvl[m] : P.capacity];
         timer_f[0] = tb.timer0[sn.timer[0]];
         timer_f[1] = tb.timer1[sn.timer[1]];
-        frac = *reinterpret_cast<const float4 *>(tb.pat + sn.st_sort * kPatStride + 8);
+        frac = Stage<GEN>::fractions(sn.st_sort, tb);
     }
     double acc[4];
     if (KIND != 2) { // get_sort_obs pieces (env_super.py:306-325)
-        const uint32_t *rec = tb.pat + sn.st_belt * kPatStride;
-        occ_f = __uint_as_float(rec[1]);
-        prop = *reinterpret_cast<const float4 *>(rec + 4);
+        occ_f = Stage<GEN>::occupancy(sn.st_belt, P, tb);
+        prop = Stage<GEN>::proportions(sn.st_belt, tb);
 #pragma unroll
         for (int m = 0; m < 4; ++m) acc[m] = NOISE ? sn.acc[m] : tb.acc[4 * sn.mode + m];
     }
@@ -1792,15 +1915,44 @@ __device__ __forceinline__ void snap_of_reset(Snap &sn, const double *cst)
 }
 
 // one env transition in one lane
-template <int KIND, bool NOISE, bool LITERAL, bool TRACE = false>
+template <int KIND, bool NOISE, bool LITERAL, bool TRACE = false, bool GEN = false>
 __device__ __forceinline__ StepResult env_step(Env &e, const Params &P, const Tables &tb, int action, int sort_mode_in,
                                                uint32_t flags, const BaleRef &bales, int k[4], float *o,
                                                Ledger *lg = nullptr)
 {
     Snap sn;
     RngLocal rng{e.rng};
-    env_dynamics<KIND, NOISE, LITERAL, RngLocal, TRACE>(e, rng, P, tb, action, sort_mode_in, flags, bales, sn, lg);
-    return env_observe<KIND, NOISE>(sn, P, tb, k, o);
+    env_dynamics<KIND, NOISE, LITERAL, RngLocal, TRACE, GEN>(e, rng, P, tb, action, sort_mode_in, flags, bales, sn, lg);
+    return env_observe<KIND, NOISE, GEN>(sn, P, tb, k, o);
+}
+
+// the generator's private stream <-> its planes (general generator mode)
+__device__ __forceinline__ void load_gen(Env &e, const uint4 *__restrict__ planes, const Params &P, long long i)
+{
+    const uint4 a = planes[(long long)PL_GEN_STATE * P.n_pad + i], b = planes[(long long)PL_GEN_INC * P.n_pad + i];
+    const uint4 x = planes[(long long)PL_GEN_AUX * P.n_pad + i];
+    e.gen.s_lo = (uint64_t)a.x | ((uint64_t)a.y << 32);
+    e.gen.s_hi = (uint64_t)a.z | ((uint64_t)a.w << 32);
+    e.gen.i_lo = (uint64_t)b.x | ((uint64_t)b.y << 32);
+    e.gen.i_hi = (uint64_t)b.z | ((uint64_t)b.w << 32);
+    e.gen_uint = x.x;
+    e.gen_has = (int)x.y;
+}
+__device__ __forceinline__ void store_gen(const Env &e, uint4 *__restrict__ planes, const Params &P, long long i)
+{
+    planes[(long long)PL_GEN_STATE * P.n_pad + i] = pack_u64x2(e.gen.s_lo, e.gen.s_hi);
+    planes[(long long)PL_GEN_INC * P.n_pad + i] = pack_u64x2(e.gen.i_lo, e.gen.i_hi);
+    planes[(long long)PL_GEN_AUX * P.n_pad + i] = make_uint4(e.gen_uint, (uint32_t)e.gen_has, 0, 0);
+}
+
+// The build's own rule for the generator a reset(seed=None) builds (the reference draws OS entropy, env_super.py:375):
+// default_rng(h) with h the hash that also picks the pattern order (unseeded_gen2).
+__device__ __forceinline__ void unseeded_generator(Env &e)
+{
+    const uint64_t h = mix64(e.rng.i_lo ^ ((uint64_t)e.episode * 0x9E3779B97F4A7C15ull));
+    e.gen = pcg_seed(h);
+    e.gen_uint = 0;
+    e.gen_has = 0;
 }
 
 } // namespace mse

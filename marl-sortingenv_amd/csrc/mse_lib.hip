@@ -166,9 +166,11 @@ __device__ __forceinline__ void stage_and_store(uint8_t *lds_base, int mask_offs
 }
 
 // auto-reset of a finished episode inside the step (reset(seed=None) semantics: streams continue)
+template <bool GEN = false>
 __device__ __forceinline__ void auto_reset_env(Env &e, const Params &P, const Tables &tb, const BaleRef &bales, int k[4])
 {
     e.gen2 = unseeded_gen2(e);
+    if (GEN) unseeded_generator(e);
     e.episode += 1u;
     reset_episode_state(e, tb.cst);
     if (P.track_bales) clear_bales(bales);
@@ -179,14 +181,13 @@ __device__ __forceinline__ void auto_reset_env(Env &e, const Params &P, const Ta
 // action for the next step: the on-device masked-uniform policy (env_monolith.py:152-158 with masking) or,
 // with MSE_ROLLOUT_RULE_BASED, the reference's rule-based policy
 // pkey = mse_policy_key(policy seed, global env index): constant over a launch (mse_policy_stream.h)
-template <int KIND>
+template <int KIND, bool GEN = false>
 __device__ __forceinline__ int policy_action(const Env &e, uint32_t cur, const Tables &tb, uint32_t flags,
                                              uint32_t pkey, uint64_t t)
 {
     if (flags & MSE_ROLLOUT_RULE_BASED) {
-        // stage id of the batch that will be on the belt: what update_environment moves from the input stage
-        const int next_belt = e.st_in;
-        return rule_based_action<KIND>(e, (int)tb.pat[next_belt * kPatStride + 2]);
+        // the batch that will be on the belt: what update_environment moves from the input stage
+        return rule_based_action<KIND>(e, Stage<GEN>::rule_mode(e.st_in, tb));
     }
     const uint32_t rr = mse_policy_word(pkey, t);
     // without masking the random mode draws from the whole action space (env_monolith.py:159-162) and the step
@@ -201,7 +202,7 @@ __device__ __forceinline__ int policy_action(const Env &e, uint32_t cur, const T
 // ==========================================================================================
 // TRACE: the launch also appends one record (include/mse.h MSE_TRACE_*) for env `trace_env` to trace_rec - the
 // opt-in single-env trace behind the reference's dashboard ledgers (mse_trace_begin).
-template <int KIND, bool NOISE, bool LITERAL, bool TRACE = false>
+template <int KIND, bool NOISE, bool LITERAL, bool TRACE = false, bool GEN = false>
 __global__ __launch_bounds__(kBlock) void k_step(Params P, uint4 *__restrict__ planes,
                                                  const uint32_t *__restrict__ table_image,
                                                  const int *__restrict__ action, const int *__restrict__ sort_mode,
@@ -229,6 +230,7 @@ __global__ __launch_bounds__(kBlock) void k_step(Params P, uint4 *__restrict__ p
     // tables while they fly (the padded planes make the state load safe for every lane)
     Env e;
     load_env<KIND, NOISE>(e, planes, P, i);
+    if (GEN) load_gen(e, planes, P, i);
     int a = live ? action[i] : 0;
     int sm = (KIND == 2 && sort_mode != nullptr && live) ? sort_mode[i] : -1;
     load_tables_to_lds(ltab, table_image, P.table_words, tid);
@@ -246,7 +248,7 @@ __global__ __launch_bounds__(kBlock) void k_step(Params P, uint4 *__restrict__ p
             lg.internal = 0;
             for (int q = 0; q < 2; ++q) lg.code[q] = lg.mat[q] = lg.bmat[q] = lg.bn[q] = lg.bq[q] = -1;
         }
-        StepResult r = env_step<KIND, NOISE, LITERAL, TRACE>(e, P, tb, a, sm, flags, bales, k, o, &lg);
+        StepResult r = env_step<KIND, NOISE, LITERAL, TRACE, GEN>(e, P, tb, a, sm, flags, bales, k, o, &lg);
         if (TRACE && i == trace_env) {
             // the state _log_step_data sees: after the step, before any auto-reset
             double *t = trace_rec;
@@ -281,11 +283,12 @@ __global__ __launch_bounds__(kBlock) void k_step(Params P, uint4 *__restrict__ p
 #pragma unroll
                 for (int j = 0; j < D; ++j) terminal_obs_out[i * D + j] = o[j];
             }
-            auto_reset_env(e, P, tb, bales, k);
-            env_obs<KIND>(e, P, tb, k, o);
+            auto_reset_env<GEN>(e, P, tb, bales, k);
+            env_obs<KIND, GEN>(e, P, tb, k, o);
         }
         mbits = action_mask_bits<KIND>(e, P);
         store_env<KIND, NOISE>(e, planes, P, i, false);
+        if (GEN) store_gen(e, planes, P, i);
         if (reward_out != nullptr) reward_out[i] = (float)r.reward;
         if (reward64_out != nullptr) reward64_out[i] = r.reward;
         if (done_out != nullptr) done_out[i] = (uint8_t)r.done;
@@ -296,7 +299,7 @@ __global__ __launch_bounds__(kBlock) void k_step(Params P, uint4 *__restrict__ p
                           mask_out ? mask_out + row0 * A : nullptr, n_valid, tid);
 }
 
-template <int KIND, bool NOISE, bool LITERAL>
+template <int KIND, bool NOISE, bool LITERAL, bool GEN = false>
 __global__ __launch_bounds__(kBlock) void k_rollout(Params P, uint4 *__restrict__ planes,
                                                     const uint32_t *__restrict__ table_image, int k_steps,
                                                     uint64_t policy_seed, uint64_t policy_t0,
@@ -329,6 +332,7 @@ __global__ __launch_bounds__(kBlock) void k_rollout(Params P, uint4 *__restrict_
     int sm = -1;
     if (live) {
         load_env<KIND, NOISE>(e, planes, P, i);
+        if (GEN) load_gen(e, planes, P, i);
         if (KIND == 2 && sort_mode != nullptr) sm = sort_mode[i];
     }
     // every load has landed before the step loop: inside it there are only stores, which nothing waits for
@@ -343,12 +347,12 @@ __global__ __launch_bounds__(kBlock) void k_rollout(Params P, uint4 *__restrict_
         uint32_t mbits = 0;
         const long long srow = (long long)s * P.n + row0;
         if (live) {
-            int a = policy_action<KIND>(e, cur_mask, tb, flags, pkey, policy_t0 + (uint64_t)s);
+            int a = policy_action<KIND, GEN>(e, cur_mask, tb, flags, pkey, policy_t0 + (uint64_t)s);
             int k[4];
-            StepResult r = env_step<KIND, NOISE, LITERAL>(e, P, tb, a, sm, flags, bales, k, o);
+            StepResult r = env_step<KIND, NOISE, LITERAL, false, GEN>(e, P, tb, a, sm, flags, bales, k, o);
             if (__builtin_expect(r.done != 0, 0)) { // every env of a batch finishes its episode on the same step: rare, wave-uniform
-                auto_reset_env(e, P, tb, bales, k);
-                env_obs<KIND>(e, P, tb, k, o);
+                auto_reset_env<GEN>(e, P, tb, bales, k);
+                env_obs<KIND, GEN>(e, P, tb, k, o);
             }
             mbits = action_mask_bits<KIND>(e, P);
             cur_mask = mbits; // what the next step's policy sees
@@ -359,7 +363,10 @@ __global__ __launch_bounds__(kBlock) void k_rollout(Params P, uint4 *__restrict_
         stage_and_store<KIND>(lds, LdsLayout<KIND>::obs_bytes, o, mbits, obs_out ? obs_out + srow * D : nullptr,
                               mask_out ? mask_out + srow * A : nullptr, n_valid, tid);
     }
-    if (live) store_env<KIND, NOISE>(e, planes, P, i, false);
+    if (live) {
+        store_env<KIND, NOISE>(e, planes, P, i, false);
+        if (GEN) store_gen(e, planes, P, i);
+    }
     if (P.track_bales) {
 #pragma unroll
         for (int m = 0; m < 5; ++m) planes[(long long)(PL_BALE0 + m) * P.n_pad + i] = lbale[m * kBlock + tid];
@@ -1069,6 +1076,9 @@ __global__ __launch_bounds__(kBlock) void k_reset(Params P, uint4 *__restrict__ 
             uint64_t r = pcg_next64(gen);
             // permutation([1,2]) swaps iff the first buffered uint32 is even (utils/input_generator.py:28-30)
             e.gen2 = (((uint32_t)r) & 1u) == 0u ? 1 : 0;
+            e.gen = gen; // the generator's stream goes on from there (observable in general generator mode only):
+            e.gen_uint = (uint32_t)(r >> 32); // the permutation took the low half, the high half is buffered
+            e.gen_has = 1;
             e.press = pcg_seed(seed + 3);
             e.press_has = 0;
             e.press_uint = 0;
@@ -1082,17 +1092,20 @@ __global__ __launch_bounds__(kBlock) void k_reset(Params P, uint4 *__restrict__ 
             planes[(long long)PL_SORTRNG_AUX * P.n_pad + i] = make_uint4(0, 0, 0, 0);
         } else {
             e.gen2 = unseeded_gen2(e);
+            unseeded_generator(e);
             e.episode += 1u;
         }
         reset_episode_state(e, tb.cst);
         clear_bales(BaleRef{planes + (long long)PL_BALE0 * P.n_pad + i, P.n_pad});
         store_env<1, true>(e, planes, P, i, reseeded);
+        store_gen(e, planes, P, i);
     }
     if (obs_out != nullptr) {
         int k[4];
         container_purity_k(e, k);
         float o[D];
-        env_obs<KIND>(e, P, tb, k, o);
+        if (P.gen_mode) env_obs<KIND, true>(e, P, tb, k, o);
+        else env_obs<KIND, false>(e, P, tb, k, o);
 #pragma unroll
         for (int j = 0; j < D; ++j) obs_out[i * D + j] = o[j];
     }
@@ -1129,11 +1142,17 @@ __global__ __launch_bounds__(kBlock) void k_sort_agent_obs(Params P, const uint4
     const Tables tb = tables_at(table_image, P); // cold kernel: tables straight from global memory
     Env e;
     load_env<2, false>(e, planes, P, i);
-    update_environment(e);
     int k[4];
     container_purity_k(e, k);
     float o[13];
-    sort_obs(e, tb, k, o);
+    if (P.gen_mode) { // a preview draws from a copy of the generator's stream: the step will draw the same
+        load_gen(e, planes, P, i);
+        update_environment<true>(e, P);
+        sort_obs<true>(e, P, tb, k, o);
+    } else {
+        update_environment<false>(e, P);
+        sort_obs<false>(e, P, tb, k, o);
+    }
 #pragma unroll
     for (int j = 0; j < 13; ++j) obs_out[i * 13 + j] = o[j];
 }
@@ -1148,9 +1167,15 @@ __global__ __launch_bounds__(kBlock) void k_press_agent_obs(Params P, const uint
     const Tables tb = tables_at(table_image, P);
     Env e;
     load_env<2, false>(e, planes, P, i);
-    update_environment(e);
     float o[16];
-    press_obs(e, P, tb, o);
+    if (P.gen_mode) {
+        load_gen(e, planes, P, i);
+        update_environment<true>(e, P);
+        press_obs<true>(e, P, tb, o);
+    } else {
+        update_environment<false>(e, P);
+        press_obs<false>(e, P, tb, o);
+    }
 #pragma unroll
     for (int j = 0; j < 16; ++j) obs_out[i * 16 + j] = o[j];
 }
@@ -1165,42 +1190,10 @@ __global__ __launch_bounds__(kBlock) void k_sample(Params P, const uint4 *__rest
     const Tables tb = tables_at(table_image, P);
     Env e;
     load_env<KIND, false>(e, planes, P, i);
-    action_out[i] = policy_action<KIND>(e, action_mask_bits<KIND>(e, P), tb, flags,
-                                        mse_policy_key(policy_seed, (uint64_t)(P.index_offset + i)), policy_t);
+    const uint32_t key = mse_policy_key(policy_seed, (uint64_t)(P.index_offset + i));
+    action_out[i] = P.gen_mode ? policy_action<KIND, true>(e, action_mask_bits<KIND>(e, P), tb, flags, key, policy_t)
+                               : policy_action<KIND, false>(e, action_mask_bits<KIND>(e, P), tb, flags, key, policy_t);
 }
-
-// numpy's Generator.choice(n) / choice(arr) without p: arr[bounded Lemire on the generator's buffered uint32]
-// (numpy _generator.pyx choice -> random_bounded_uint64 -> buffered_bounded_lemire_uint32); no draw when n == 1
-struct Rng32 {
-    Pcg g;
-    uint32_t uinteger;
-    int has;
-    __device__ __forceinline__ uint32_t next32()
-    {
-        if (has) {
-            has = 0;
-            return uinteger;
-        }
-        const uint64_t r = pcg_next64(g);
-        has = 1;
-        uinteger = (uint32_t)(r >> 32);
-        return (uint32_t)r;
-    }
-    __device__ __forceinline__ uint32_t lemire(uint32_t n) // uniform in [0, n), n >= 1
-    {
-        if (n <= 1u) return 0u;
-        uint64_t m = (uint64_t)next32() * n;
-        uint32_t leftover = (uint32_t)m;
-        if (leftover < n) {
-            const uint32_t threshold = (0xFFFFFFFFu - (n - 1u)) % n;
-            while (leftover < threshold) {
-                m = (uint64_t)next32() * n;
-                leftover = (uint32_t)m;
-            }
-        }
-        return (uint32_t)(m >> 32);
-    }
-};
 
 // Env_3_Monolith.step(mode='model') with no agents assigned (env_monolith.py:186-221): the sorting decision is
 // rng_sorting.choice([0, 1]), the press action rng_pressing.choice(flatnonzero(press_action_masks())) with masking
@@ -1312,6 +1305,14 @@ __global__ __launch_bounds__(kBlock) void k_get_state(Params P, const uint4 *__r
         w[21] = (uint64_t)si.x | ((uint64_t)si.y << 32);
         w[22] = sa.y;
         w[23] = sa.x;
+        const uint4 gs = planes[(long long)PL_GEN_STATE * P.n_pad + i], gi = planes[(long long)PL_GEN_INC * P.n_pad + i];
+        const uint4 ga = planes[(long long)PL_GEN_AUX * P.n_pad + i];
+        w[24] = (uint64_t)gs.z | ((uint64_t)gs.w << 32);
+        w[25] = (uint64_t)gs.x | ((uint64_t)gs.y << 32);
+        w[26] = (uint64_t)gi.z | ((uint64_t)gi.w << 32);
+        w[27] = (uint64_t)gi.x | ((uint64_t)gi.y << 32);
+        w[28] = ga.y;
+        w[29] = ga.x;
     }
 }
 
@@ -1336,7 +1337,7 @@ __global__ __launch_bounds__(kBlock) void k_set_state(Params P, uint4 *__restric
             e.ct[m] = (int)r[12 + m];
             e.cf[m] = (int)r[16 + m];
         }
-        for (int s = 0; s < 3; ++s)
+        for (int s = 0; s < 3 && !P.gen_mode; ++s)
             if (w[s] != P.pat_word[0] && w[s] != P.pat_word[1] && w[s] != P.pat_word[2]) atomicAdd(err_count, 1ull);
         e.st_in = stage_id(w[0], P);
         e.st_belt = stage_id(w[1], P);
@@ -1373,6 +1374,9 @@ __global__ __launch_bounds__(kBlock) void k_set_state(Params P, uint4 *__restric
         planes[(long long)PL_SORTRNG_STATE * P.n_pad + i] = pack_u64x2(w[19], w[18]);
         planes[(long long)PL_SORTRNG_INC * P.n_pad + i] = pack_u64x2(w[21], w[20]);
         planes[(long long)PL_SORTRNG_AUX * P.n_pad + i] = make_uint4((uint32_t)w[23], (uint32_t)w[22], 0, 0);
+        planes[(long long)PL_GEN_STATE * P.n_pad + i] = pack_u64x2(w[25], w[24]);
+        planes[(long long)PL_GEN_INC * P.n_pad + i] = pack_u64x2(w[27], w[26]);
+        planes[(long long)PL_GEN_AUX * P.n_pad + i] = make_uint4((uint32_t)w[29], (uint32_t)w[28], 0, 0);
         e.rng.s_hi = w[0]; e.rng.s_lo = w[1]; e.rng.i_hi = w[2]; e.rng.i_lo = w[3];
         e.noise.s_hi = w[6]; e.noise.s_lo = w[7]; e.noise.i_hi = w[8]; e.noise.i_lo = w[9];
         e.press.s_hi = w[12]; e.press.s_lo = w[13]; e.press.i_hi = w[14]; e.press.i_lo = w[15];
@@ -1442,11 +1446,9 @@ static int build_tables(const mse_config &c, Params &P, std::vector<uint32_t> &i
             w |= (uint32_t)cnt << (8 * m);
             sum += cnt;
         }
-        if (k > 0 && sum != c.input_batch_size) {
-            why = "input_batch_size leaves a floor() remainder for a seasonal pattern: the generator's random "
-                  "remainder draws (utils/input_generator.py:50-55) are not on the restated path";
-            return MSE_ERR_UNSUPPORTED_CONFIG;
-        }
+        // utils/input_generator.py:49-55: units the floor()s leave over go to random materials - general generator mode
+        P.gen_rem[k] = k > 0 ? c.input_batch_size - sum : 0;
+        if (P.gen_rem[k] != 0) P.gen_mode = 1;
         P.pat_word[k] = w;
         auto f32_bits = [](float v) {
             uint32_t u;
@@ -1468,7 +1470,11 @@ static int build_tables(const mse_config &c, Params &P, std::vector<uint32_t> &i
     }
     P.pat_word1 = P.pat_word[1];
     P.pat_word2 = P.pat_word[2];
-    if (P.pat_word[1] == P.pat_word[2] || P.pat_word[1] == 0 || P.pat_word[2] == 0) {
+    {
+        const float occ = host_clip_f((float)((double)c.input_batch_size / 100.0), -1.0f, 1.0f); // env_super.py:456, :318
+        std::memcpy(&P.occ_nonempty, &occ, 4);
+    }
+    if (!P.gen_mode && (P.pat_word[1] == P.pat_word[2] || P.pat_word[1] == 0 || P.pat_word[2] == 0)) {
         why = "the two seasonal patterns must give distinct, non-empty material counts";
         return MSE_ERR_UNSUPPORTED_CONFIG;
     }
@@ -1590,6 +1596,14 @@ static int build_tables(const mse_config &c, Params &P, std::vector<uint32_t> &i
             Ainv = Ainv * Minv;
         }
     }
+    P.off_gprop = P.off_gfrac = 0;
+    if (P.gen_mode) { // per-count tables: every batch holds input_batch_size units, so a share is a function of the count
+        P.off_gprop = (int)image.size();
+        for (int k = 0; k < 256; ++k)
+            put_f32(host_clip_f((float)((double)k / (double)c.input_batch_size), -1.0f, 1.0f));
+        P.off_gfrac = (int)image.size();
+        for (int k = 0; k < 256; ++k) put_f32(host_clip_f((float)((double)k / (double)c.stage_capacity), 0.0f, 1.0f));
+    }
     while (image.size() & 3u) image.push_back(0u); // copied to LDS in 16-byte pieces
     P.table_words = (int)image.size();
     if (P.table_words > 16384) {
@@ -1620,26 +1634,30 @@ static void launch_step(mse_env *h, hipStream_t s, const int32_t *action, const 
     const size_t lds = lds_bytes_step<KIND>(h);
     if (h->trace_rec != nullptr) { // the traced variant: one more record for env trace_env
         double *rec = h->trace_rec + h->trace_count * MSE_TRACE_COLS;
-#define MSE_LAUNCH_STEP_T(NOISE, LIT)                                                                    \
-    hipLaunchKernelGGL((k_step<KIND, NOISE, LIT, true>), grid_of(h), dim3(kBlock), lds, s, h->P, h->planes, h->tables, \
+#define MSE_LAUNCH_STEP_T(NOISE, LIT, GEN)                                                               \
+    hipLaunchKernelGGL((k_step<KIND, NOISE, LIT, true, GEN>), grid_of(h), dim3(kBlock), lds, s, h->P, h->planes, h->tables, \
                        action, sort_mode, flags, obs, rew, rew64, done, mask, tobs, h->err_count, rec, (long long)h->trace_env)
+#define MSE_LAUNCH_STEP_TG(NOISE, LIT) do { if (h->P.gen_mode) MSE_LAUNCH_STEP_T(NOISE, LIT, true); else MSE_LAUNCH_STEP_T(NOISE, LIT, false); } while (0)
         if (h->noise_on) {
-            if (lit) MSE_LAUNCH_STEP_T(true, true); else MSE_LAUNCH_STEP_T(true, false);
+            if (lit) MSE_LAUNCH_STEP_TG(true, true); else MSE_LAUNCH_STEP_TG(true, false);
         } else {
-            if (lit) MSE_LAUNCH_STEP_T(false, true); else MSE_LAUNCH_STEP_T(false, false);
+            if (lit) MSE_LAUNCH_STEP_TG(false, true); else MSE_LAUNCH_STEP_TG(false, false);
         }
+#undef MSE_LAUNCH_STEP_TG
 #undef MSE_LAUNCH_STEP_T
         h->trace_count += 1;
         return;
     }
-#define MSE_LAUNCH_STEP(NOISE, LIT)                                                                      \
-    hipLaunchKernelGGL((k_step<KIND, NOISE, LIT>), grid_of(h), dim3(kBlock), lds, s, h->P, h->planes, h->tables, \
+#define MSE_LAUNCH_STEP(NOISE, LIT, GEN)                                                                 \
+    hipLaunchKernelGGL((k_step<KIND, NOISE, LIT, false, GEN>), grid_of(h), dim3(kBlock), lds, s, h->P, h->planes, h->tables, \
                        action, sort_mode, flags, obs, rew, rew64, done, mask, tobs, h->err_count, (double *)nullptr, -1LL)
+#define MSE_LAUNCH_STEP_G(NOISE, LIT) do { if (h->P.gen_mode) MSE_LAUNCH_STEP(NOISE, LIT, true); else MSE_LAUNCH_STEP(NOISE, LIT, false); } while (0)
     if (h->noise_on) {
-        if (lit) MSE_LAUNCH_STEP(true, true); else MSE_LAUNCH_STEP(true, false);
+        if (lit) MSE_LAUNCH_STEP_G(true, true); else MSE_LAUNCH_STEP_G(true, false);
     } else {
-        if (lit) MSE_LAUNCH_STEP(false, true); else MSE_LAUNCH_STEP(false, false);
+        if (lit) MSE_LAUNCH_STEP_G(false, true); else MSE_LAUNCH_STEP_G(false, false);
     }
+#undef MSE_LAUNCH_STEP_G
 #undef MSE_LAUNCH_STEP
 }
 
@@ -1681,14 +1699,16 @@ static void launch_rollout(mse_env *h, hipStream_t s, int k_steps, uint64_t poli
         return;
     }
     const size_t lds = lds_bytes_rollout<KIND>(h);
-#define MSE_LAUNCH_ROLLOUT(NOISE, LIT)                                                                   \
-    hipLaunchKernelGGL((k_rollout<KIND, NOISE, LIT>), grid_of(h), dim3(kBlock), lds, s, h->P, h->planes, h->tables, \
+#define MSE_LAUNCH_ROLLOUT(NOISE, LIT, GEN)                                                              \
+    hipLaunchKernelGGL((k_rollout<KIND, NOISE, LIT, GEN>), grid_of(h), dim3(kBlock), lds, s, h->P, h->planes, h->tables, \
                        k_steps, policy_seed, h->policy_t, sort_mode, flags, actions, obs, rew, done, mask)
+#define MSE_LAUNCH_ROLLOUT_G(NOISE, LIT) do { if (h->P.gen_mode) MSE_LAUNCH_ROLLOUT(NOISE, LIT, true); else MSE_LAUNCH_ROLLOUT(NOISE, LIT, false); } while (0)
     if (h->noise_on) {
-        if (lit) MSE_LAUNCH_ROLLOUT(true, true); else MSE_LAUNCH_ROLLOUT(true, false);
+        if (lit) MSE_LAUNCH_ROLLOUT_G(true, true); else MSE_LAUNCH_ROLLOUT_G(true, false);
     } else {
-        if (lit) MSE_LAUNCH_ROLLOUT(false, true); else MSE_LAUNCH_ROLLOUT(false, false);
+        if (lit) MSE_LAUNCH_ROLLOUT_G(false, true); else MSE_LAUNCH_ROLLOUT_G(false, false);
     }
+#undef MSE_LAUNCH_ROLLOUT_G
 #undef MSE_LAUNCH_ROLLOUT
 }
 
@@ -1890,6 +1910,14 @@ int mse_create_indexed(mse_env **out, const mse_config *cfg, int64_t n_envs, int
     }
     h->pipelined = cfg->rollout_pipeline == 1 || cfg->rollout_pipeline == 3 ||
                    (cfg->rollout_pipeline == 0 && n_envs <= (int64_t)kPoEnvs * cus);
+    if (P.gen_mode) { // general generator mode: the multi-role kernels carry stage ids, not counts
+        if (cfg->rollout_pipeline == 1 || cfg->rollout_pipeline == 3) {
+            delete h;
+            return fail(MSE_ERR_UNSUPPORTED_CONFIG, "rollout_pipeline 1 / 3 need a remainder-free input_batch_size (the "
+                                                    "one-lane kernels serve the general generator)");
+        }
+        h->pipelined = false;
+    }
     {
         // draws per step are bounded by the mis-sorted units of the two stations a mode leaves unboosted at the
         // lowest accuracy the noise allows; the ring kernel needs that bound <= kRingMaxPerStep
@@ -2085,9 +2113,10 @@ int mse_rollout_policy(mse_env *h, mse_policy *pol, int32_t k_steps, uint64_t se
     if (pol->device != h->device) return fail(MSE_ERR_INVALID_ARGUMENT, "policy and env live on different devices");
     if ((obs_out && !aligned16(obs_out)) || (mask_out && !aligned16(mask_out)))
         return fail(MSE_ERR_ALIGNMENT, "obs_out / mask_out must be 16-byte aligned");
-    if (h->literal)
-        return fail(MSE_ERR_UNSUPPORTED_CONFIG, "mse_rollout_policy serves the integer draw path only (literal_choice / "
-                                                "input_batch_size > 127 handles: alternate mse_policy_forward and mse_step)");
+    if (h->literal || h->P.gen_mode)
+        return fail(MSE_ERR_UNSUPPORTED_CONFIG, "mse_rollout_policy serves the integer draw path with a remainder-free batch "
+                                                "(literal_choice, input_batch_size > 127 or with a floor() remainder: "
+                                                "alternate mse_policy_forward and mse_step)");
     hipStream_t s = static_cast<hipStream_t>(stream);
     int rc;
     switch (h->P.env_kind) {

@@ -61,6 +61,15 @@ def scenarios():
             ("sort_cfgA_n5_masked_s6_s9", "sort", dict(max_steps=60, noise_sorting=0.05, balesize=150), [6, 9], "masked_uniform", True, 75),
             ("mono_cfgA_n0_greedy_s7", "mono", dict(max_steps=80, noise_sorting=0.0, balesize=150), [7, 13], "greedy_press", True, 85)):
         S.append((name, kind, kw, seeds, policy, masking, False, seg, CONFIG_A))
+    # a batch size whose floor() leaves units over (0.35 * 90 = 31.49..., 0.15 * 90 = 13.5): the generator's private
+    # stream becomes observable - remainder units by rng.choice, the shuffle's draws in between
+    # (utils/input_generator.py:46-61); `rng` then holds five streams, the generator's last
+    for name, kind, kw, seeds, policy, masking, seg in (
+            ("mono_cfgB_n5_masked_s2_s11", "mono", dict(max_steps=60, noise_sorting=0.05, balesize=200), [2, 11], "masked_uniform", True, 75),
+            ("press_cfgB_n0_unmasked_s4_s8", "press", dict(max_steps=60, noise_sorting=0.0, balesize=200), [4, 8], "ignore_mask_uniform", False, 75),
+            ("sort_cfgB_n5_masked_s6_s9", "sort", dict(max_steps=60, noise_sorting=0.05, balesize=200), [6, 9], "masked_uniform", True, 75),
+            ("mono_cfgC_n0_greedy_s7_batch77", "mono", dict(max_steps=80, noise_sorting=0.0, balesize=150), [7, 13], "greedy_press", True, 85)):
+        S.append((name, kind, kw, seeds, policy, masking, False, seg, CONFIG_C if "cfgC" in name else CONFIG_B))
     return S
 
 
@@ -74,6 +83,10 @@ CONFIG_A = {
                              "overflow_penalty_mild": -0.1, "bale_efficiency_factor": 0.8, "max_state_reward": 0.4},
                 "overflow_termination_penalty": -7.5},
 }
+
+
+CONFIG_B = {"simulation": {"input_batch_size": 90}}
+CONFIG_C = {"simulation": {"input_batch_size": 77}, "sorting_station": {"baseline_accuracy": [0.7, 0.8, 0.65, 0.9], "boost": 0.2}}
 
 
 def _construct(cls, seed, kw, overrides):

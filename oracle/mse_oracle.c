@@ -459,11 +459,15 @@ void orc_env_reset(orc_env *e, int has_seed, uint64_t seed, float *obs_out)
 
     /* new SeasonalInputGenerator(seed=seed) with the default steps_per_pattern (env_super.py:375) */
     if (has_seed) {
-        e->gen_first = orc_permutation12_first(seed);
+        /* utils/input_generator.py:26-30: default_rng(seed), then permutation([1, 2]) = one next_uint32 */
+        orc_pcg64_seed(&e->rng_gen, seed);
+        e->gen_first = (orc_pcg64_next32(&e->rng_gen) & 1u) ? 1 : 2;
         env_set_seed(e, seed); /* env_super.py:377-378 */
         e->episode = 1;        /* episodes are counted from the last seeded reset */
     } else {
+        /* the build's rule for the OS-entropy generator of reset(seed=None): pattern order and stream from one hash */
         e->gen_first = unseeded_first_pattern(e);
+        orc_pcg64_seed(&e->rng_gen, mix64(e->rng.inc_lo ^ ((uint64_t)e->episode * 0x9E3779B97F4A7C15ull)));
         e->episode++;
     }
     e->gen_idx = 0;
@@ -492,10 +496,21 @@ void orc_env_reset(orc_env *e, int has_seed, uint64_t seed, float *obs_out)
  *  step pieces
  * ====================================================================================== */
 
-/* utils/input_generator.py:37-64 generate_input, reduced to the material counts that
- * update_environment keeps (env_super.py:448-453).  The generator's private shuffle never
- * reaches the step path.  Only remainder-free batch sizes are restated; with config.yml's
- * 100 units the floor() leaves no remainder. */
+/* utils/input_generator.py:37-64 generate_input, reduced to the material counts that update_environment keeps
+ * (env_super.py:448-453).  When floor(ratio * batch) leaves units over, each goes to rng.choice(material_names)
+ * (:49-55) and the batch list is shuffled (:58-61): Generator.shuffle of a Python list draws random_interval(i) for
+ * i = n-1 .. 1 (masked rejection on next_uint32) - its result is never read, but the draws move the generator's private
+ * stream.  With a remainder-free batch (config.yml's 100) nothing of that stream is ever observed and it is left alone. */
+static int gen_has_remainder(const orc_config *c)
+{
+    for (int key = 0; key < 2; ++key) {
+        int sum = 0;
+        for (int m = 0; m < 4; ++m) sum += (int)floor(c->pattern_ratio[key][m] * (double)c->input_batch_size);
+        if (sum != c->input_batch_size) return 1;
+    }
+    return 0;
+}
+
 static int generate_counts(orc_env *e, int32_t counts[4])
 {
     if (e->gen_counter >= 20) { /* reset() builds the generator with the default 20 */
@@ -508,8 +523,22 @@ static int generate_counts(orc_env *e, int32_t counts[4])
         counts[m] = (int32_t)floor(e->cfg.pattern_ratio[key - 1][m] * (double)e->cfg.input_batch_size);
         sum += counts[m];
     }
+    if (gen_has_remainder(&e->cfg)) {
+        for (int r = sum; r < e->cfg.input_batch_size; ++r) /* :53-55 */
+            counts[orc_pcg64_integers(&e->rng_gen, 0, 4)] += 1;
+        for (uint32_t i = (uint32_t)e->cfg.input_batch_size - 1u; i > 0u; --i) { /* :61 shuffle -> random_interval(i) */
+            uint32_t mask = i;
+            mask |= mask >> 1;
+            mask |= mask >> 2;
+            mask |= mask >> 4;
+            mask |= mask >> 8;
+            mask |= mask >> 16;
+            while ((orc_pcg64_next32(&e->rng_gen) & mask) > i) {
+            }
+        }
+    }
     e->gen_counter++;
-    return sum == e->cfg.input_batch_size ? 0 : -1;
+    return 0;
 }
 
 /* env_super.py:433-461 update_environment */
@@ -936,6 +965,7 @@ void orc_env_snapshot(const orc_env *e, int64_t *I, double *D, uint64_t *R)
     pack_rng(&e->rng_noise, R + 6);
     pack_rng(&e->rng_pressing, R + 12);
     pack_rng(&e->rng_sorting, R + 18);
+    pack_rng(&e->rng_gen, R + 24);
 }
 
 /* ====================================================================================== *

@@ -102,6 +102,7 @@ typedef struct {
 
     /* RNG streams (env_super.py:170-174) */
     orc_pcg64 rng_input, rng_sorting, rng_pressing, rng_noise, rng;
+    orc_pcg64 rng_gen; /* the SeasonalInputGenerator's private default_rng(seed) (utils/input_generator.py:28) */
 
     /* identity for the build's own unseeded-reset rule (see orc_env_reset) */
     uint32_t episode;
@@ -149,8 +150,8 @@ int  orc_env_num_actions(const orc_env *e);
 /* snapshot: fixed layout shared with tests (see oracle/oracle.py SNAP_*) */
 #define ORC_SNAP_INTS 71
 #define ORC_SNAP_DBLS 8
-#define ORC_SNAP_RNG_WORDS 24 /* rng, rng_noise, rng_pressing, rng_sorting x 6 words */
-void orc_env_snapshot(const orc_env *e, int64_t *ints, double *dbls, uint64_t *rng_words /*[4*6]*/);
+#define ORC_SNAP_RNG_WORDS 30 /* rng, rng_noise, rng_pressing, rng_sorting, input generator x 6 words */
+void orc_env_snapshot(const orc_env *e, int64_t *ints, double *dbls, uint64_t *rng_words /*[5*6]*/);
 
 /* Env_3_Monolith.step(mode='model') with no agents assigned (env_monolith.py:186-221): draws the sorting decision
  * from rng_sorting.choice([0, 1]) and the press action from rng_pressing.choice(valid) (masked) or

@@ -18,7 +18,7 @@ ENV_SORT, ENV_PRESS, ENV_MONO = 1, 2, 3
 KIND_BY_NAME = {"sort": ENV_SORT, "press": ENV_PRESS, "mono": ENV_MONO}
 STEP_UNMASKED, STEP_CHECK_OVERFLOW, STEP_SANITIZE_LATE = 1, 2, 8
 
-SNAP_INTS, SNAP_DBLS, SNAP_RNG_WORDS = 71, 8, 24  # rng words: rng, rng_noise, rng_pressing, rng_sorting x 6
+SNAP_INTS, SNAP_DBLS, SNAP_RNG_WORDS = 71, 8, 30  # rng words: rng, rng_noise, rng_pressing, rng_sorting, input generator x 6
 # integer snapshot layout (orc_env_snapshot)
 SNAP = {
     "input": slice(0, 4), "belt": slice(4, 8), "sorting": slice(8, 12),

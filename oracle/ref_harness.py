@@ -163,7 +163,7 @@ def snapshot(env):
     D[0:4] = env.accuracy_belt
     D[4:8] = env.accuracy_sorter
     R = np.array(_rng_words(env.rng) + _rng_words(env.rng_noise) + _rng_words(env.rng_pressing) +
-                 _rng_words(env.rng_sorting), dtype=np.uint64)
+                 _rng_words(env.rng_sorting) + _rng_words(env.input_generator.rng), dtype=np.uint64)
     return I, D, R
 
 

@@ -125,10 +125,17 @@ def test_c_abi_error_behaviour():
     assert rc == -6 and b"aligned" in L.mse_last_error()
     with pytest.raises(MseError):
         env.rollout(0)
-    # configurations outside the restated path are refused loudly at create time
-    cfg = M.SortingEnvConfig(input_batch_size=90)  # floor() remainder -> generator RNG draws
+    # a batch size with a floor() remainder runs the generator's private stream on the device (general generator
+    # mode, golden fixtures *_cfgB_* / *_cfgC_*): served by the one-lane kernels; asking for a multi-role kernel or
+    # for the fused policy rollout is refused loudly
+    cfg = M.SortingEnvConfig(input_batch_size=90)
+    gen = M.BatchedSortingEnv(kind="mono", num_envs=4, config=cfg)
+    gen.rollout(3)
     with pytest.raises(MseError) as ei:
-        M.BatchedSortingEnv(kind="mono", num_envs=4, config=cfg)
+        M.BatchedSortingEnv(kind="mono", num_envs=4, config=cfg, rollout_pipeline=3)
+    assert ei.value.status == -2
+    with pytest.raises(MseError) as ei:
+        M.BatchedSortingEnv(kind="mono", num_envs=4, config=M.SortingEnvConfig(input_batch_size=300))
     assert ei.value.status == -2
 
 

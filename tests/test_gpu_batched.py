@@ -344,3 +344,74 @@ def test_extreme_sizes():
     for _ in range(3):
         small.rollout(4, policy_seed=2024, buffers=sb)
     assert torch.equal(bufs["obs"][:, :65536], sb["obs"]) and torch.equal(bufs["reward"][:, :65536], sb["reward"])
+
+
+def _gen_configs(batch):
+    """(package config, oracle config maker) for a batch size whose floor() leaves units over: general generator mode"""
+    import marl_sortingenv_amd as M
+    from oracle.oracle import default_config
+
+    def oracle_cfg(kind, max_steps, noise):
+        c = default_config(kind, max_steps, noise, 200)
+        c.input_batch_size = batch
+        return c
+    return M.SortingEnvConfig(input_batch_size=batch), oracle_cfg
+
+
+@pytest.mark.parametrize("kind,batch,noise", [("mono", 90, 0.05), ("press", 77, 0.0), ("sort", 90, 0.05)])
+def test_general_generator_mode_vs_oracle_with_autoreset(kind, batch, noise):
+    """input_batch_size with a floor() remainder (utils/input_generator.py:46-61): the generator's private stream runs
+    on the device - remainder units by choice, the shuffle's draws - through seeded resets AND auto-resets (the build's
+    unseeded rule for the stream, shared with the oracle); state incl. that stream compared every few steps."""
+    import torch
+
+    n, T, base = 200, 100, 500
+    cfg, oracle_cfg = _gen_configs(batch)
+    env = _mk(kind, n, base_seed=base, max_steps=35, noise_sorting=noise, balesize=200, auto_reset=True, config=cfg)
+    oracles = [OracleEnv(kind=kind, seed=base + i, cfg=oracle_cfg(kind, 35, noise)) for i in range(n)]
+    obs0 = env.obs.cpu().numpy()
+    for i, o in enumerate(oracles):
+        assert np.array_equal(obs0[i], o.reset(base + i))
+    g = torch.Generator(device="cpu").manual_seed(3)
+    for t in range(T):
+        mask = env.action_masks().cpu().numpy()
+        act = torch.multinomial(torch.as_tensor(mask, dtype=torch.float32), 1, generator=g).squeeze(1).to(torch.int32)
+        if kind == "press" and t % 2:  # the preview of the sorting agent's observation draws from a COPY of the stream
+            pre = env.sort_agent_obs().cpu().numpy()
+            for i, o in enumerate(oracles):
+                assert np.array_equal(pre[i].view(np.uint32), o.sort_agent_obs().view(np.uint32)), (t, i)
+        obs, rew, done, m2 = env.step(act, want_reward64=True)
+        obs, done, r64 = obs.cpu().numpy(), done.cpu().numpy(), env.reward64.cpu().numpy()
+        for i, o in enumerate(oracles):
+            eo, er, et = o.step(int(act[i]))
+            if et:
+                eo = o.reset(None)
+            assert abs(er - r64[i]) <= 1e-6 and bool(done[i]) == et, (t, i)
+            assert np.array_equal(obs[i].view(np.uint32), eo.view(np.uint32)), (t, i, obs[i], eo)
+        if t % 9 == 0 or t == T - 1:
+            _compare_state(env, oracles)
+            rng = env.get_state()[2].cpu().numpy().view(np.uint64)
+            for i, o in enumerate(oracles):
+                assert np.array_equal(rng[i, 24:30], o.snapshot()[2][24:30]), (t, i)
+    assert env.error_count() == 0
+
+
+@pytest.mark.parametrize("kind,policy", [("mono", "random"), ("mono", "rule_based"), ("press", "random"), ("sort", "random")])
+def test_general_generator_rollout_equals_step(kind, policy):
+    """the fused rollout kernel in general generator mode == single steps fed with its actions (random and the
+    reference's rule-based policy, whose sorting_rules() is evaluated literally on the drawn counts)"""
+    import torch
+
+    n, K = 700, 50
+    cfg, _ = _gen_configs(90)
+    kw = dict(base_seed=5, max_steps=20, noise_sorting=0.05, balesize=200, auto_reset=True, config=cfg)
+    a, b = _mk(kind, n, **kw), _mk(kind, n, **kw)
+    buf = a.rollout(K, policy_seed=99, policy=policy)
+    for k in range(K):
+        if policy == "rule_based":
+            assert torch.equal(b.rule_actions(), buf["actions"][k])
+        obs, rew, done, mask = b.step(buf["actions"][k])
+        assert torch.equal(obs, buf["obs"][k]) and torch.equal(rew, buf["reward"][k])
+        assert torch.equal(done, buf["done"][k]) and torch.equal(mask, buf["mask"][k])
+    for x, y in zip(a.get_state(), b.get_state()):
+        assert torch.equal(x, y)

@@ -63,8 +63,15 @@ class GpuDriver:
         return ints[0].cpu().numpy(), d, rng[0].cpu().numpy().view(np.uint64)
 
 
+GENERATOR_WORDS = list(range(24, 30))  # the input generator's private stream: only advanced (and compared) when the
+                                       # fixture's batch size leaves a floor() remainder
+
+
 def _skip_words(meta):
-    return ALWAYS_SKIP_WORDS + (NOISE_WORDS if meta["noise_sorting"] == 0.0 else [])
+    batch = ((meta.get("config_overrides") or {}).get("simulation") or {}).get("input_batch_size", 100)
+    remainder_free = all(sum(int(np.floor(r * batch)) for r in p) == batch
+                         for p in ((0.40, 0.15, 0.35, 0.10), (0.15, 0.40, 0.10, 0.35)))
+    return ALWAYS_SKIP_WORDS + (NOISE_WORDS if meta["noise_sorting"] == 0.0 else []) + (GENERATOR_WORDS if remainder_free else [])
 
 
 @pytest.mark.parametrize("path", replay.fixtures(), ids=lambda p: os.path.basename(p)[:-4])

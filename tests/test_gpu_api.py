@@ -148,7 +148,7 @@ def test_rule_based_policy_matches_reference_benchmark():
 
     z = np.load(os.path.join(replay.GOLDEN_DIR, "rule_based_mono_n0_seeds1_10.npz"))
     seeds, T = z["seeds"], z["actions"].shape[1]
-    for pipeline in (1, 2):
+    for pipeline in (3, 0, 1, 2):  # 3 = the three-role ring kernel (the shipped headline kernel), 0 = the default choice
         env = M.BatchedSortingEnv(kind="mono", num_envs=len(seeds), seeds=torch.as_tensor(seeds), max_steps=T,
                                   noise_sorting=0.0, balesize=200, rollout_pipeline=pipeline)
         first = env.rule_actions().cpu().numpy()

@@ -216,10 +216,18 @@ def main():
     singles.sort()
     barrier()
     torch.cuda.synchronize(dev)
+    # one HIP event before the first launch of the region and one after the last (an event pair per pass would put two
+    # event records between consecutive launches: ~10 us per 80 us launch at --steps 20)
     events = []
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    per_pass = args.steps // chunk + (1 if args.steps % chunk else 0)
     t0 = time.perf_counter()
+    ev0.record(stream)
     for _ in range(reps):
-        run(args.steps, events)
+        run(args.steps)
+    ev1.record(stream)
+    if args.mode != "step":
+        events.append((per_pass * reps, args.steps * reps, ev0, ev1))
     torch.cuda.synchronize(dev)
     barrier()
     torch.cuda.synchronize(dev)

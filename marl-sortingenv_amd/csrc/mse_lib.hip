@@ -1002,12 +1002,12 @@ __global__ __launch_bounds__(512) void k_rollout_policy(Params P, uint4 *__restr
         }
         // ---- policy.  swap(o[2q], o[2q+1]) = {tile 0's k-step q operand, tile 1's}: lanes 32-63 of tile 0 get the
         // odd entries of the envs in lanes 0-31, lanes 0-31 of tile 1 the even entries of the envs in lanes 32-63
-        float x0[16], x1[16];
+        float x[2][16];
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(o[2 * q]), __float_as_uint(o[2 * q + 1]), false, false);
-            x0[q] = __uint_as_float(r[0]);
-            x1[q] = __uint_as_float(r[1]);
+            x[0][q] = __uint_as_float(r[0]);
+            x[1][q] = __uint_as_float(r[1]);
         }
         // without masking (plain PPO on the unmasked env) the policy samples from the whole action space and the
         // step sanitises; the recorded mask row is action_masks() either way
@@ -1015,14 +1015,16 @@ __global__ __launch_bounds__(512) void k_rollout_policy(Params P, uint4 *__restr
         msep::both_halves_u32((flags & MSE_STEP_UNMASKED) ? ((1u << A) - 1u) : mbits, mb0, mb1);
         const uint64_t t = policy_t0 + (uint64_t)s;
         const bool det = deterministic != 0 || tail;
-        const msep::TileOut p0 = msep::policy_tile<NR, F16X3>(wl, lane, x0, legal_of(mb0), det, mse_policy_word(key0, t), nullptr);
-        int a = p0.action;
-        float logp = p0.logp, value = p0.value;
-        if (TILES == 2) {
-            const msep::TileOut p1 = msep::policy_tile<NR, F16X3>(wl, lane, x1, legal_of(mb1), det, mse_policy_word(key1, t), nullptr);
-            a = h ? p1.action : a; // lane l is env l: tile l >> 5, column l & 31 (results are valid in both halves)
-            logp = h ? p1.logp : logp;
-            value = h ? p1.value : value;
+        const uint32_t legal[2] = {legal_of(mb0), legal_of(mb1)};
+        const uint32_t words[2] = {mse_policy_word(key0, t), mse_policy_word(key1, t)};
+        msep::TileOut p[2];
+        msep::policy_tiles<NR, F16X3, TILES>(wl, lane, x, legal, det, words, nullptr, p);
+        int a = p[0].action;
+        float logp = p[0].logp, value = p[0].value;
+        if (TILES == 2) { // lane l is env l: tile l >> 5, column l & 31 (results are valid in both halves)
+            a = h ? p[1].action : a;
+            logp = h ? p[1].logp : logp;
+            value = h ? p[1].value : value;
         }
         if (tail) {
             if (live && last_value_out != nullptr) last_value_out[i] = value;

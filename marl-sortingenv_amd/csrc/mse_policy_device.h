@@ -101,29 +101,6 @@ __device__ __forceinline__ float sigmoid2(float z)
     return __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(z) + 1.0f);
 }
 
-// one layer: acc = bias; acc += W[:, k-step s] (x) in[s] for the 16 k-steps.  `in` are 16 registers of this lane.
-__device__ __forceinline__ f32x16 layer(lds_f4 wl, int lane, int h, int L, const float *in)
-{
-    f32x16 acc;
-    lds_f4 b = wl + (kOffB + (L * 2 + h) * 16) / 4; // the same 64 bytes for every lane of a half: LDS broadcast
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const f32x4 v = b[g];
-        acc[4 * g + 0] = v[0];
-        acc[4 * g + 1] = v[1];
-        acc[4 * g + 2] = v[2];
-        acc[4 * g + 3] = v[3];
-    }
-    lds_f4 w = wl + (kOffW + L * 16 * 64) / 4 + lane; // [group][lane]: 16 bytes per lane, conflict-free
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const f32x4 a = w[g * 64];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q], in[4 * g + q], acc, 0, 0, 0);
-    }
-    return acc;
-}
-
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef __fp16 pk16x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -153,98 +130,93 @@ __device__ __forceinline__ void split16(const float *in, u32x4 hi[2], u32x4 lo[2
     }
 }
 
-// one layer on the f16x3 split: acc = bias; acc += W_lo in_hi + W_hi in_lo + W_hi in_hi  (small terms first)
-__device__ __forceinline__ f32x16 layer16(lds_f4 wl, int lane, int h, int L, const u32x4 hi[2], const u32x4 lo[2])
+// The B operands of one layer for T tiles.  The f32 form keeps the 16 inputs as they are; the f16x3 form splits them.
+template <bool F16X3, int T>
+struct Operands;
+template <int T>
+struct Operands<false, T> {
+    float v[T][16];
+    __device__ __forceinline__ void set(int t, const float *in)
+    {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[t][r] = in[r];
+    }
+};
+template <int T>
+struct Operands<true, T> {
+    u32x4 hi[T][2], lo[T][2];
+    __device__ __forceinline__ void set(int t, const float *in) { split16(in, hi[t], lo[t]); }
+};
+
+// One layer for T tiles: acc[t] = bias; acc[t] += W in[t].  The A operands (weights) are read from LDS once and serve
+// every tile; the T accumulation chains are independent, so one tile's MFMAs run behind the other's.
+// f32 form: 16 k-steps of v_mfma_f32_32x32x2_f32.  f16x3 form: per 16-k chunk  W_lo in_hi + W_hi in_lo + W_hi in_hi
+// (small terms first) on v_mfma_f32_32x32x16_f16.
+template <int T>
+__device__ __forceinline__ void bias_init(lds_f4 wl, int h, int L, f32x16 acc[T])
 {
-    f32x16 acc;
-    lds_f4 b = wl + (kOffB + (L * 2 + h) * 16) / 4;
+    lds_f4 b = wl + (kOffB + (L * 2 + h) * 16) / 4; // the same 64 bytes for every lane of a half: LDS broadcast
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         const f32x4 v = b[g];
-        acc[4 * g + 0] = v[0];
-        acc[4 * g + 1] = v[1];
-        acc[4 * g + 2] = v[2];
-        acc[4 * g + 3] = v[3];
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            acc[t][4 * g + 0] = v[0];
+            acc[t][4 * g + 1] = v[1];
+            acc[t][4 * g + 2] = v[2];
+            acc[t][4 * g + 3] = v[3];
+        }
     }
-    lds_u4 wh = (lds_u4)(wl + kOffW / 4) + (L * 2) * 64 + lane;  // [hi | lo][layer][chunk][lane]: 16 bytes per lane
+}
+template <int T>
+__device__ __forceinline__ void apply_layer(lds_f4 wl, int lane, int h, int L, const Operands<false, T> &op, f32x16 acc[T])
+{
+    bias_init<T>(wl, h, L, acc);
+    lds_f4 w = wl + (kOffW + L * 16 * 64) / 4 + lane; // [group][lane]: 16 bytes per lane, conflict-free
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const f32x4 a = w[g * 64];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+#pragma unroll
+            for (int t = 0; t < T; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q], op.v[t][4 * g + q], acc[t], 0, 0, 0);
+        }
+    }
+}
+template <int T>
+__device__ __forceinline__ void apply_layer(lds_f4 wl, int lane, int h, int L, const Operands<true, T> &op, f32x16 acc[T])
+{
+    bias_init<T>(wl, h, L, acc);
+    lds_u4 wh = (lds_u4)(wl + kOffW / 4) + (L * 2) * 64 + lane; // [hi | lo][layer][chunk][lane]: 16 bytes per lane
     lds_u4 wlo = wh + 5 * 2 * 64;
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
         const f16x8 ah = __builtin_bit_cast(f16x8, (u32x4)wh[c * 64]);
         const f16x8 al = __builtin_bit_cast(f16x8, (u32x4)wlo[c * 64]);
-        const f16x8 bh = __builtin_bit_cast(f16x8, hi[c]);
-        const f16x8 bl = __builtin_bit_cast(f16x8, lo[c]);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, __builtin_bit_cast(f16x8, op.hi[t][c]), acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, __builtin_bit_cast(f16x8, op.lo[t][c]), acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, __builtin_bit_cast(f16x8, op.hi[t][c]), acc[t], 0, 0, 0);
     }
-    return acc;
 }
-
-template <bool F16X3>
-struct Operand;
-template <>
-struct Operand<false> { // the f32 form keeps the 16 inputs as they are
-    const float *in;
-    __device__ __forceinline__ void set(const float *v) { in = v; }
-    __device__ __forceinline__ f32x16 apply(lds_f4 wl, int lane, int h, int L) const { return layer(wl, lane, h, L, in); }
-};
-template <>
-struct Operand<true> {
-    u32x4 hi[2], lo[2];
-    __device__ __forceinline__ void set(const float *v) { split16(v, hi, lo); }
-    __device__ __forceinline__ f32x16 apply(lds_f4 wl, int lane, int h, int L) const { return layer16(wl, lane, h, L, hi, lo); }
-};
 
 struct TileOut {
     int action;   // valid in both halves of the column
     float logp, value;
 };
 
-// x[16]: layer-1 B operands of this lane (register s = observation entry 2 s + h of env j);
-// legal: bit r set iff the action in accumulator register r (row row_of(r, h)) exists and may be taken;
-// word: the env's 32-bit draw for this step.  lgm_out (optional): the masked logits of this lane's registers.
-template <int NR, bool F16X3>
-__device__ __forceinline__ TileOut policy_tile(lds_f4 wl, int lane, const float *x, uint32_t legal, bool deterministic,
-                                               uint32_t word, float *lgm_out)
+// masked softmax + sample of one tile.  lg: the head's accumulator; legal: bit r set iff the action in accumulator
+// register r (row row_of(r, h)) exists and may be taken; word: the env's 32-bit draw for this step.
+template <int NR>
+__device__ __forceinline__ void sample_tile(const f32x16 &lg, int h, uint32_t legal, bool deterministic, uint32_t word,
+                                            float *lgm_out, TileOut &out)
 {
-    const int h = lane >> 5;
-    TileOut out;
-    Operand<F16X3> xin, op;
-    xin.set(x); // both networks read the observation: split it once
-    // ---- critic: 2 hidden layers and the value head --------------------------------------------------------
-    float hid[16];
-    {
-        f32x16 a = xin.apply(wl, lane, h, 3);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) hid[r] = sigmoid2(a[r]);
-        op.set(hid);
-        a = op.apply(wl, lane, h, 4);
-        lds_f4 wv = wl + (kOffWV + h * 16) / 4;
-        float v = 0.0f;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const f32x4 w4 = wv[g];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) v = fmaf(sigmoid2(a[4 * g + q]), w4[q], v);
-        }
-        const Halves hv = both_halves(v);
-        const float bv = (*(wl + kOffBV / 4))[0];
-        out.value = (hv.lo + hv.hi) + bv;
-    }
-    // ---- actor ------------------------------------------------------------------------------------------------
-    f32x16 lg;
-    {
-        f32x16 a = xin.apply(wl, lane, h, 0);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) hid[r] = sigmoid2(a[r]);
-        op.set(hid);
-        a = op.apply(wl, lane, h, 1);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) hid[r] = sigmoid2(a[r]);
-        op.set(hid);
-        lg = op.apply(wl, lane, h, 2);
-    }
     // masked logits of the NR registers that can hold an action: illegal -> -1e8 (sb3_contrib's HUGE_NEG)
     float lgm[NR];
 #pragma unroll
@@ -312,7 +284,102 @@ __device__ __forceinline__ TileOut policy_tile(lds_f4 wl, int lane, const float 
     out.action = (int)(take_hi ? a_hi : a_lo);
     const float la_f = take_hi ? l2.hi : l2.lo;
     out.logp = (la_f - m) - __builtin_amdgcn_logf(total) * 0.693147180559945309417f; // v_log_f32 = log2
-    return out;
+}
+
+// value head of one tile: the critic's second hidden layer (pre-activation c2) . wv + bv
+__device__ __forceinline__ float value_tile(lds_f4 wl, int h, const f32x16 &c2)
+{
+    lds_f4 wv = wl + (kOffWV + h * 16) / 4;
+    float v = 0.0f;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const f32x4 w4 = wv[g];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v = fmaf(sigmoid2(c2[4 * g + q]), w4[q], v);
+    }
+    const Halves hv = both_halves(v);
+    const float bv = (*(wl + kOffBV / 4))[0];
+    return (hv.lo + hv.hi) + bv;
+}
+
+// T tiles through the actor-critic network.  x[t][16]: layer-1 B operands of this lane for tile t (register s =
+// observation entry 2 s + h of env j); legal[t], word[t]: see sample_tile; lgm_out (optional): [T][NR].
+// The arithmetic of a tile does not depend on T or on the order below (every tile's operations are its own); the order
+// only decides what overlaps: with one tile the critic's and the actor's layers alternate, with two the tiles do.
+template <int NR, bool F16X3, int T>
+__device__ __forceinline__ void policy_tiles(lds_f4 wl, int lane, const float (*x)[16], const uint32_t *legal, bool deterministic,
+                                             const uint32_t *word, float *lgm_out, TileOut *out)
+{
+    const int h = lane >> 5;
+    Operands<F16X3, T> xin; // both networks read the observation: split it once
+#pragma unroll
+    for (int t = 0; t < T; ++t) xin.set(t, x[t]);
+    f32x16 lg[T];
+    if (T == 1) {
+        Operands<F16X3, T> opc, opa;
+        float hc[16], ha[16];
+        f32x16 c1[T], a1[T], c2[T], a2[T];
+        apply_layer<T>(wl, lane, h, 3, xin, c1);
+        apply_layer<T>(wl, lane, h, 0, xin, a1);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) hc[r] = sigmoid2(c1[0][r]);
+        opc.set(0, hc);
+        apply_layer<T>(wl, lane, h, 4, opc, c2);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ha[r] = sigmoid2(a1[0][r]);
+        opa.set(0, ha);
+        apply_layer<T>(wl, lane, h, 1, opa, a2);
+        out[0].value = value_tile(wl, h, c2[0]);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ha[r] = sigmoid2(a2[0][r]);
+        opa.set(0, ha);
+        apply_layer<T>(wl, lane, h, 2, opa, lg);
+    } else {
+        Operands<F16X3, T> op;
+        float hid[16];
+        f32x16 acc[T], acc2[T];
+        apply_layer<T>(wl, lane, h, 3, xin, acc); // critic
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) hid[r] = sigmoid2(acc[t][r]);
+            op.set(t, hid);
+        }
+        apply_layer<T>(wl, lane, h, 4, op, acc2);
+        apply_layer<T>(wl, lane, h, 0, xin, acc); // the actor's first layer runs behind the value heads
+#pragma unroll
+        for (int t = 0; t < T; ++t) out[t].value = value_tile(wl, h, acc2[t]);
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) hid[r] = sigmoid2(acc[t][r]);
+            op.set(t, hid);
+        }
+        apply_layer<T>(wl, lane, h, 1, op, acc2);
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) hid[r] = sigmoid2(acc2[t][r]);
+            op.set(t, hid);
+        }
+        apply_layer<T>(wl, lane, h, 2, op, lg);
+    }
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+        sample_tile<NR>(lg[t], h, legal[t], deterministic, word[t], lgm_out == nullptr ? nullptr : lgm_out + t * NR, out[t]);
+}
+
+// one tile (the standalone forward)
+template <int NR, bool F16X3>
+__device__ __forceinline__ TileOut policy_tile(lds_f4 wl, int lane, const float *x, uint32_t legal, bool deterministic,
+                                               uint32_t word, float *lgm_out)
+{
+    float xs[1][16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) xs[0][r] = x[r];
+    TileOut out[1];
+    policy_tiles<NR, F16X3, 1>(wl, lane, xs, &legal, deterministic, &word, lgm_out, out);
+    return out[0];
 }
 
 } // namespace msep

@@ -300,9 +300,12 @@ int mse_policy_forward(mse_policy *policy, int64_t n, int64_t index_offset, cons
  * step, the bootstrap of compute_returns_and_advantage) and last_done_out u8[N].  Any output may be NULL.  The
  * observation never leaves the wave's registers between env_step and the policy's MFMA chain.  Bit-identical to
  * alternating mse_policy_forward and mse_step with the same seed and step counter.
- *   sort_mode_dev i32[N] or NULL: Env_2's per-env sorting decision (NULL = sorting_rules()).
+ *   sort_policy   Env_2 only, or NULL: a second network (13 -> 2) standing where the reference expects the pre-trained
+ *                 sorting agent (env_2_press.py:101-104: sort_agent.predict(get_sort_obs() after the step's flow update,
+ *                 deterministic=True)): its actor is evaluated inside the loop, argmax (f16x3 form of both networks);
+ *   sort_mode_dev i32[N] or NULL: else Env_2's per-env sorting decision (both NULL = sorting_rules()).
  *   flags: MSE_STEP_UNMASKED, MSE_STEP_CHECK_OVERFLOW.  Needs auto_reset=1; advances the policy step counter by K. */
-int mse_rollout_policy(mse_env *env, mse_policy *policy, int32_t k_steps, uint64_t seed, int deterministic,
+int mse_rollout_policy(mse_env *env, mse_policy *policy, mse_policy *sort_policy, int32_t k_steps, uint64_t seed, int deterministic,
                        const int32_t *sort_mode_dev, uint32_t flags, float *obs_out, uint8_t *mask_out,
                        int32_t *actions_out, float *logp_out, float *value_out, float *reward_out,
                        uint8_t *episode_start_out, float *last_value_out, uint8_t *last_done_out, void *stream);

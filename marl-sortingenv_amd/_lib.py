@@ -116,7 +116,7 @@ def load_library(path: str | None = None) -> C.CDLL:
     L.mse_policy_set_precision.argtypes = [vp, C.c_int]
     L.mse_policy_precision.argtypes = [vp]
     L.mse_policy_forward.argtypes = [vp, i64, i64, vp, vp, u64, u64, C.c_int, vp, vp, vp, vp, vp]
-    L.mse_rollout_policy.argtypes = [vp, vp, i32, u64, C.c_int, vp, u32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.mse_rollout_policy.argtypes = [vp, vp, vp, i32, u64, C.c_int, vp, u32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     if path is None:
         _lib = L
     else:

@@ -76,15 +76,19 @@ class PolicyRolloutCollector:
 
 class FusedPolicyRollout:
     """K steps of policy forward + env transition per launch (`mse_rollout_policy`): MaskableRolloutBuffer-shaped
-    device tensors [K, N, ...].  `sort_mode`: Env_2's per-env sorting decisions (None = the reference's rule)."""
+    device tensors [K, N, ...].  Env_2's sorting decisions: `sort_policy` (a 13 -> 2 MlpPolicy standing for the
+    pre-trained sorting agent, evaluated inside the kernel), else `sort_mode` (a per-env tensor), else the reference's rule."""
 
     def __init__(self, env: BatchedSortingEnv, policy: MlpPolicy, n_steps: int, seed: int = 2024,
-                 sort_mode: Optional[torch.Tensor] = None):
+                 sort_mode: Optional[torch.Tensor] = None, sort_policy: Optional[MlpPolicy] = None):
         if policy.obs_dim != env.obs_dim or policy.n_actions != env.num_actions:
             raise ValueError("policy dimensions do not match the env")
+        if sort_policy is not None and (env.kind != "press" or sort_policy.obs_dim != 13 or sort_policy.n_actions != 2):
+            raise ValueError("a sorting policy (13 -> 2) only applies to Env_2_Pressing")
         if not env.auto_reset:
             raise ValueError("collection needs auto_reset=True (episodes end inside a rollout)")
         self.env, self.policy, self.n_steps, self.seed = env, policy, int(n_steps), int(seed)
+        self.sort_policy = sort_policy  # Env_2's pre-trained sorting agent, evaluated inside the kernel
         self.sort_mode = None if sort_mode is None else sort_mode.to(device=env.device, dtype=torch.int32).contiguous()
         n, K, dev = env.num_envs, self.n_steps, env.device
         self.buffers = {
@@ -117,7 +121,8 @@ class FusedPolicyRollout:
             return None if x is None else C.c_void_p(x.data_ptr())
 
         with torch.cuda.device(env.device):
-            check(env.L.mse_rollout_policy(env._h, self.policy._h, K, self.seed, 1 if deterministic else 0,
+            check(env.L.mse_rollout_policy(env._h, self.policy._h, None if self.sort_policy is None else self.sort_policy._h,
+                                           K, self.seed, 1 if deterministic else 0,
                                            ptr(self.sort_mode), flags, ptr(b["observations"]), ptr(b["action_masks"]),
                                            ptr(b["actions"]), ptr(b["log_probs"]), ptr(b["values"]), ptr(b["rewards"]),
                                            ptr(b["episode_starts"]), ptr(b["last_values"]), ptr(b["last_dones"]),

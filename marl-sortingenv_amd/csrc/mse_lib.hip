@@ -919,10 +919,13 @@ __device__ __forceinline__ void wave_store_rows_mask(uint8_t *ltile, uint32_t mb
 // TILES = 1: a wave owns 32 envs in lanes 0-31 (lanes 32-63 only carry the other k-half of the MFMA operands): twice
 //            the waves for the same batch - the shape for batches that would otherwise leave one wave per SIMD, where
 //            a single wave issues one vector instruction per ~5 cycles and a second wave's come for free.
-template <int KIND, bool NOISE, int TILES, bool F16X3>
+// SORTPOL (Env_2 only): a second network (13 -> 2, its actor evaluated deterministically) plays the pre-trained sorting
+// agent of env_2_press.py:101-104 inside the loop: it sees get_sort_obs() of the coming step's flow update.
+template <int KIND, bool NOISE, int TILES, bool F16X3, bool SORTPOL = false>
 __global__ __launch_bounds__(512) void k_rollout_policy(Params P, uint4 *__restrict__ planes,
                                                         const uint32_t *__restrict__ table_image,
-                                                        const float *__restrict__ weight_blob, int k_steps,
+                                                        const float *__restrict__ weight_blob,
+                                                        const float *__restrict__ sort_weight_blob, int k_steps,
                                                         uint64_t policy_seed, uint64_t policy_t0, int deterministic,
                                                         const int *__restrict__ sort_mode, uint32_t flags,
                                                         float *__restrict__ obs_out, uint8_t *__restrict__ mask_out,
@@ -936,10 +939,11 @@ __global__ __launch_bounds__(512) void k_rollout_policy(Params P, uint4 *__restr
     constexpr int D = L::D, A = L::A, NR = msep::regs_for_actions(A), ENVS = L::ENVS;
     uint8_t *lds = reinterpret_cast<uint8_t *>(mse_dyn_lds);
     float *lw = reinterpret_cast<float *>(lds);
-    uint32_t *ltab = reinterpret_cast<uint32_t *>(lds + L::weight_bytes);
+    constexpr int kWeightBytes = L::weight_bytes * (SORTPOL ? 2 : 1); // [policy image][sorting policy image]
+    uint32_t *ltab = reinterpret_cast<uint32_t *>(lds + kWeightBytes);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, n_waves = blockDim.x >> 6;
     const int table_bytes = P.table_words * 4;
-    uint8_t *lwave = lds + L::weight_bytes + table_bytes + wave * L::wave_bytes;
+    uint8_t *lwave = lds + kWeightBytes + table_bytes + wave * L::wave_bytes;
     uint4 *lbale = reinterpret_cast<uint4 *>(lwave + L::tile_bytes);
     const long long wave_row0 = ((long long)blockIdx.x * n_waves + wave) * ENVS;
     const bool wave_active = wave_row0 < P.n_pad; // the planes are padded to 256 envs: the last workgroup may overhang
@@ -950,6 +954,7 @@ __global__ __launch_bounds__(512) void k_rollout_policy(Params P, uint4 *__restr
     const int n_valid = rem >= ENVS ? ENVS : (rem > 0 ? (int)rem : 0);
 
     msep_copy_image(lw, weight_blob, F16X3, tid, blockDim.x);
+    if (SORTPOL) msep_copy_image(lw + msep::kLdsFloats, sort_weight_blob, F16X3, tid, blockDim.x);
     for (int w = tid; w < P.table_words / 4; w += blockDim.x)
         reinterpret_cast<uint4 *>(ltab)[w] = reinterpret_cast<const uint4 *>(table_image)[w];
     const BaleRef bales{lbale + (env_lane ? lane : 0), ENVS};
@@ -972,12 +977,13 @@ __global__ __launch_bounds__(512) void k_rollout_policy(Params P, uint4 *__restr
 #pragma unroll
     for (int j = 0; j < 32; ++j) o[j] = 0.0f;
     uint32_t mbits = 0;
+    int kcur[4] = {101, 101, 101, 101}; // container purities of the current state (the sorting agent's view needs them)
     if (live) {
-        int k0[4];
-        container_purity_k(e, k0);
-        env_obs<KIND>(e, P, tb, k0, o);
+        container_purity_k(e, kcur);
+        env_obs<KIND>(e, P, tb, kcur, o);
         mbits = action_mask_bits<KIND>(e, P);
     }
+    msep::lds_f4 wl_sort = (msep::lds_f4)(__attribute__((address_space(3))) float *)(lw + msep::kLdsFloats);
     // policy stream keys of the env(s) this lane serves as an MFMA column: tile t = envs 32 t .. 32 t + 31 of the wave
     const int h = lane >> 5, col = lane & 31;
     const uint32_t key0 = mse_policy_key(policy_seed, (uint64_t)(P.index_offset + wave_row0 + col));
@@ -1031,6 +1037,28 @@ __global__ __launch_bounds__(512) void k_rollout_policy(Params P, uint4 *__restr
             if (live && last_done_out != nullptr) last_done_out[i] = (uint8_t)last_done;
             break;
         }
+        if (SORTPOL) {
+            // the sorting agent's decision for the coming step: get_sort_obs() one flow update ahead (a copy steps
+            // the flow; env_step will take the same step), through the second network's actor, argmax
+            float so[32];
+#pragma unroll
+            for (int j = 0; j < 32; ++j) so[j] = 0.0f;
+            if (live) {
+                Env ec = e;
+                update_environment<false>(ec, P);
+                sort_obs<false>(ec, P, tb, kcur, so);
+            }
+            float sx[2][16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(so[2 * q]), __float_as_uint(so[2 * q + 1]), false, false);
+                sx[0][q] = __uint_as_float(r[0]);
+                sx[1][q] = __uint_as_float(r[1]);
+            }
+            int sa[2];
+            msep::actor_argmax2_tiles<F16X3, TILES>(wl_sort, lane, sx, sa);
+            sm = (TILES == 2 && h) ? sa[1] : sa[0];
+        }
         // ---- the env transition under that action
         if (live) {
             int k[4];
@@ -1039,6 +1067,8 @@ __global__ __launch_bounds__(512) void k_rollout_policy(Params P, uint4 *__restr
                 auto_reset_env(e, P, tb, bales, k);
                 env_obs<KIND>(e, P, tb, k, o);
             }
+#pragma unroll
+            for (int m = 0; m < 4; ++m) kcur[m] = k[m];
             mbits = action_mask_bits<KIND>(e, P);
             last_done = r.done;
             const long long at = (long long)s * P.n + i;
@@ -1715,8 +1745,8 @@ static void launch_rollout(mse_env *h, hipStream_t s, int k_steps, uint64_t poli
 }
 
 template <int KIND>
-static int launch_rollout_policy(mse_env *h, const mse_policy *pol, hipStream_t s, int k_steps, uint64_t seed,
-                                 int deterministic, const int32_t *sort_mode, uint32_t flags, float *obs, uint8_t *mask,
+static int launch_rollout_policy(mse_env *h, const mse_policy *pol, const mse_policy *sort_pol, hipStream_t s, int k_steps,
+                                 uint64_t seed, int deterministic, const int32_t *sort_mode, uint32_t flags, float *obs, uint8_t *mask,
                                  int32_t *actions, float *logp, float *value, float *rew, uint8_t *start,
                                  float *last_value, uint8_t *last_done)
 {
@@ -1735,12 +1765,25 @@ static int launch_rollout_policy(mse_env *h, const mse_policy *pol, hipStream_t 
     const long long envs_per_wg = 32LL * tiles * n_waves;
     const dim3 grid((unsigned)((h->P.n + envs_per_wg - 1) / envs_per_wg)), block((unsigned)(64 * n_waves));
     const size_t wave_bytes = tiles == 1 ? PolLayout<KIND, 1>::wave_bytes : PolLayout<KIND, 2>::wave_bytes;
-    const size_t lds = (size_t)msep::kLdsFloats * 4u + (size_t)h->P.table_words * 4u + (size_t)n_waves * wave_bytes;
+    const size_t lds = (size_t)msep::kLdsFloats * 4u * (sort_pol ? 2u : 1u) + (size_t)h->P.table_words * 4u + (size_t)n_waves * wave_bytes;
     if (lds > (size_t)160 * 1024) return MSE_ERR_UNSUPPORTED_CONFIG;
+    if (KIND == 2 && sort_pol != nullptr) { // Env_2 with its sorting agent in the loop (f16x3 form of both networks)
+#define MSE_LAUNCH_RPS(NOISE, TILES)                                                                                 \
+    hipLaunchKernelGGL((k_rollout_policy<2, NOISE, TILES, true, true>), grid, block, lds, s, h->P, h->planes, h->tables, \
+                       pol->blob, sort_pol->blob, k_steps, seed, h->policy_t, deterministic, sort_mode, flags, obs, mask, \
+                       actions, logp, value, rew, start, last_value, last_done)
+        if (tiles == 1) {
+            if (h->noise_on) MSE_LAUNCH_RPS(true, 1); else MSE_LAUNCH_RPS(false, 1);
+        } else {
+            if (h->noise_on) MSE_LAUNCH_RPS(true, 2); else MSE_LAUNCH_RPS(false, 2);
+        }
+#undef MSE_LAUNCH_RPS
+        return MSE_OK;
+    }
 #define MSE_LAUNCH_RP(NOISE, TILES, F16)                                                                             \
     hipLaunchKernelGGL((k_rollout_policy<KIND, NOISE, TILES, F16>), grid, block, lds, s, h->P, h->planes, h->tables, \
-                       pol->blob, k_steps, seed, h->policy_t, deterministic, sort_mode, flags, obs, mask, actions,   \
-                       logp, value, rew, start, last_value, last_done)
+                       pol->blob, (const float *)nullptr, k_steps, seed, h->policy_t, deterministic, sort_mode, flags, obs, \
+                       mask, actions, logp, value, rew, start, last_value, last_done)
     if (!f16) {
         if (h->noise_on) MSE_LAUNCH_RP(true, 2, false); else MSE_LAUNCH_RP(false, 2, false);
     } else if (tiles == 1) {
@@ -2097,7 +2140,7 @@ int mse_rollout(mse_env *h, int32_t k_steps, uint64_t policy_seed, const int32_t
     return MSE_OK;
 }
 
-int mse_rollout_policy(mse_env *h, mse_policy *pol, int32_t k_steps, uint64_t seed, int deterministic,
+int mse_rollout_policy(mse_env *h, mse_policy *pol, mse_policy *sort_pol, int32_t k_steps, uint64_t seed, int deterministic,
                        const int32_t *sort_mode, uint32_t flags, float *obs_out, uint8_t *mask_out, int32_t *actions_out,
                        float *logp_out, float *value_out, float *reward_out, uint8_t *episode_start_out,
                        float *last_value_out, uint8_t *last_done_out, void *stream)
@@ -2113,6 +2156,13 @@ int mse_rollout_policy(mse_env *h, mse_policy *pol, int32_t k_steps, uint64_t se
     if (pol->d_in != mse_obs_dim(h) || pol->n_act != mse_num_actions(h))
         return fail(MSE_ERR_INVALID_ARGUMENT, "the policy's observation / action dimensions do not match the env kind");
     if (pol->device != h->device) return fail(MSE_ERR_INVALID_ARGUMENT, "policy and env live on different devices");
+    if (sort_pol != nullptr) {
+        if (h->P.env_kind != MSE_ENV_PRESS || sort_pol->d_in != 13 || sort_pol->n_act != 2)
+            return fail(MSE_ERR_INVALID_ARGUMENT, "a sorting policy (13 -> 2) only applies to Env_2_Pressing");
+        if (sort_mode != nullptr) return fail(MSE_ERR_INVALID_ARGUMENT, "give sort_mode_dev or a sorting policy, not both");
+        if (!pol->use_f16() || !sort_pol->use_f16() || sort_pol->device != h->device)
+            return fail(MSE_ERR_UNSUPPORTED_CONFIG, "the in-loop sorting policy exists in the f16x3 form of both networks, on the env's device");
+    }
     if ((obs_out && !aligned16(obs_out)) || (mask_out && !aligned16(mask_out)))
         return fail(MSE_ERR_ALIGNMENT, "obs_out / mask_out must be 16-byte aligned");
     if (h->literal || h->P.gen_mode)
@@ -2122,9 +2172,9 @@ int mse_rollout_policy(mse_env *h, mse_policy *pol, int32_t k_steps, uint64_t se
     hipStream_t s = static_cast<hipStream_t>(stream);
     int rc;
     switch (h->P.env_kind) {
-    case 1: rc = launch_rollout_policy<1>(h, pol, s, k_steps, seed, deterministic, sort_mode, flags, obs_out, mask_out, actions_out, logp_out, value_out, reward_out, episode_start_out, last_value_out, last_done_out); break;
-    case 2: rc = launch_rollout_policy<2>(h, pol, s, k_steps, seed, deterministic, sort_mode, flags, obs_out, mask_out, actions_out, logp_out, value_out, reward_out, episode_start_out, last_value_out, last_done_out); break;
-    default: rc = launch_rollout_policy<3>(h, pol, s, k_steps, seed, deterministic, sort_mode, flags, obs_out, mask_out, actions_out, logp_out, value_out, reward_out, episode_start_out, last_value_out, last_done_out); break;
+    case 1: rc = launch_rollout_policy<1>(h, pol, sort_pol, s, k_steps, seed, deterministic, sort_mode, flags, obs_out, mask_out, actions_out, logp_out, value_out, reward_out, episode_start_out, last_value_out, last_done_out); break;
+    case 2: rc = launch_rollout_policy<2>(h, pol, sort_pol, s, k_steps, seed, deterministic, sort_mode, flags, obs_out, mask_out, actions_out, logp_out, value_out, reward_out, episode_start_out, last_value_out, last_done_out); break;
+    default: rc = launch_rollout_policy<3>(h, pol, sort_pol, s, k_steps, seed, deterministic, sort_mode, flags, obs_out, mask_out, actions_out, logp_out, value_out, reward_out, episode_start_out, last_value_out, last_done_out); break;
     }
     if (rc != MSE_OK) return fail(rc, "the policy rollout kernel's LDS image does not fit this config's tables");
     MSE_CHECK_LAUNCH();

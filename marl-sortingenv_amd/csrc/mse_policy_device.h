@@ -369,6 +369,41 @@ __device__ __forceinline__ void policy_tiles(lds_f4 wl, int lane, const float (*
         sample_tile<NR>(lg[t], h, legal[t], deterministic, word[t], lgm_out == nullptr ? nullptr : lgm_out + t * NR, out[t]);
 }
 
+// The actor alone, argmax of a two-action head, for T tiles: what Env_2_Pressing.step asks its sorting agent
+// (sort_agent.predict(sort_obs, deterministic=True), env_2_press.py:101-104).  Same layers, same bits as policy_tiles;
+// rows 0 and 1 sit in registers 0 and 1 of half 0, ties go to action 0 as in sample_tile.
+template <bool F16X3, int T>
+__device__ __forceinline__ void actor_argmax2_tiles(lds_f4 wl, int lane, const float (*x)[16], int *action)
+{
+    const int h = lane >> 5;
+    Operands<F16X3, T> xin, op;
+#pragma unroll
+    for (int t = 0; t < T; ++t) xin.set(t, x[t]);
+    float hid[16];
+    f32x16 acc[T], acc2[T];
+    apply_layer<T>(wl, lane, h, 0, xin, acc);
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) hid[r] = sigmoid2(acc[t][r]);
+        op.set(t, hid);
+    }
+    apply_layer<T>(wl, lane, h, 1, op, acc2);
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) hid[r] = sigmoid2(acc2[t][r]);
+        op.set(t, hid);
+    }
+    apply_layer<T>(wl, lane, h, 2, op, acc);
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        uint32_t lo, hi;
+        both_halves_u32(acc[t][1] > acc[t][0] ? 1u : 0u, lo, hi); // half 0 holds rows 0 and 1
+        action[t] = (int)lo;
+    }
+}
+
 // one tile (the standalone forward)
 template <int NR, bool F16X3>
 __device__ __forceinline__ TileOut policy_tile(lds_f4 wl, int lane, const float *x, uint32_t legal, bool deterministic,

@@ -249,3 +249,31 @@ def test_fused_policy_rollout_equals_two_launch_collector(kind, noise, n, K, pre
     # deterministic (argmax) collection agrees as well
     x, y = two.collect(deterministic=True), fused.collect(deterministic=True)
     assert torch.equal(x["actions"], y["actions"]) and torch.equal(x["rewards"], y["rewards"])
+
+
+@pytest.mark.parametrize("n,noise", [(3000, 0.05), (70300, 0.0)])
+def test_fused_rollout_with_the_sorting_agent_in_the_loop(n, noise):
+    """Env_2_Pressing with its pre-trained sorting agent (env_2_press.py:101-104) as a second network inside the
+    rollout kernel == the two-launch collector, which evaluates that network on mse_sort_agent_obs every step."""
+    import torch
+
+    import marl_sortingenv_amd as M
+
+    K = 12
+    kw = dict(kind="press", num_envs=n, device=0, base_seed=23, max_steps=9, noise_sorting=noise, balesize=200)
+    a, b = M.BatchedSortingEnv(**kw), M.BatchedSortingEnv(**kw)
+    pol = M.MlpPolicy(16, 11, _weights(16, 11, seed=41), device=0)
+    sort_pol = M.MlpPolicy(13, 2, _weights(13, 2, seed=42), device=0)
+    two = M.PolicyRolloutCollector(a, pol, K, sort_policy=sort_pol, seed=8)
+    fused = M.FusedPolicyRollout(b, pol, K, seed=8, sort_policy=sort_pol)
+    for it in range(3):
+        x, y = two.collect(), fused.collect()
+        for key in ("observations", "action_masks", "episode_starts", "actions", "log_probs", "values", "rewards",
+                    "last_values", "last_dones"):
+            assert torch.equal(x[key], y[key]), (it, key)
+        for sa, sb in zip(a.get_state(), b.get_state()):
+            assert torch.equal(sa, sb), it
+    # the sorting decisions matter: a different sorting network gives different rollouts
+    other = M.FusedPolicyRollout(M.BatchedSortingEnv(**kw), pol, K, seed=8, sort_policy=M.MlpPolicy(13, 2, _weights(13, 2, seed=43), device=0))
+    fresh = M.FusedPolicyRollout(M.BatchedSortingEnv(**kw), pol, K, seed=8, sort_policy=sort_pol)
+    assert not torch.equal(other.collect()["rewards"], fresh.collect()["rewards"])

@@ -997,6 +997,7 @@ __global__ __launch_bounds__(512) void k_rollout_policy(Params P, uint4 *__restr
 
     int last_done = 0;
     for (int s = 0; s <= k_steps; ++s) {
+        __builtin_amdgcn_s_setprio(TILES == 2 ? 3 : 0); // policy phase (see below)
         const bool tail = s == k_steps; // one more forward after the last step: the bootstrap value of the final state
         const long long srow = (long long)s * P.n + wave_row0;
         if (!tail) {
@@ -1037,6 +1038,12 @@ __global__ __launch_bounds__(512) void k_rollout_policy(Params P, uint4 *__restr
             if (live && last_done_out != nullptr) last_done_out[i] = (uint8_t)last_done;
             break;
         }
+        // Phase priorities: the two waves of a SIMD fall into step with each other (both in the policy, both in the
+        // dynamics) and then compete for the same pipe; letting one phase win the issue arbitration pulls them apart so
+        // that one wave's MFMA chains run under the other's dynamics.  Which phase should win was measured on the box
+        // (same-box A/B, 16 steps per launch): 64-env waves +8 % with the policy phase high, 32-env waves +8 % with the
+        // dynamics phase high (the other choice +4 ... 6 % each; a static per-wave priority: nothing).
+        __builtin_amdgcn_s_setprio(TILES == 2 ? 0 : 3);
         if (SORTPOL) {
             // the sorting agent's decision for the coming step: get_sort_obs() one flow update ahead (a copy steps
             // the flow; env_step will take the same step), through the second network's actor, argmax

@@ -75,7 +75,7 @@ def measured_traffic(args, n, steps_per_launch):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/r02/traffic.json,
     else r01's: FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate --pmc runs, tools/prof_traffic.sh); only quoted for the
     exact workload and steps per launch it was collected on, else null."""
-    if (args.kind, n, args.noise, args.mode, args.no_outputs) != ("mono", 65536, 0.0, "rollout", False):
+    if (args.kind, args.noise, args.mode, args.no_outputs) != ("mono", 0.0, "rollout", False):
         return None
     for rnd in ("r02", "r01"):
         try:
@@ -85,7 +85,8 @@ def measured_traffic(args, n, steps_per_launch):
             continue
         entries = t.get("entries") or [t]
         for e in entries:
-            if int(e.get("steps_per_launch", -1)) == int(steps_per_launch) and e.get("policy", "random") == args.policy:
+            if int(e.get("steps_per_launch", -1)) == int(steps_per_launch) and e.get("policy", "random") == args.policy \
+                    and int(e.get("envs", 65536)) == n:
                 return e.get("hbm_bytes_per_launch")
     return None
 

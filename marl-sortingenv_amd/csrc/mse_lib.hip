@@ -10,6 +10,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -1470,6 +1471,14 @@ static bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 
 // with -ffp-contract=off), so a device lookup returns exactly what the reference computes.
 // ------------------------------------------------------------------------------------------
 static inline double host_round2(double x) { return std::nearbyint(x * 100.0) / 100.0; } // round(np.float64, 2)
+// Python's round(float, 2): correctly rounded on the exact binary value, ties to even (glibc's printf rounds the same
+// way) - what the reference computes where the operand is a plain Python float read from config.yml
+static inline double host_round2_py(double x)
+{
+    char buf[64];
+    std::snprintf(buf, sizeof buf, "%.2f", x);
+    return std::strtod(buf, nullptr);
+}
 static inline float host_clip_f(float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
 static int build_tables(const mse_config &c, Params &P, std::vector<uint32_t> &image, std::string &why)
@@ -1557,8 +1566,11 @@ static int build_tables(const mse_config &c, Params &P, std::vector<uint32_t> &i
     P.off_pdiff = (int)image.size(); // env_super.py:212-227, 771-791, 325
     for (int m = 0; m < 4; ++m) {
         for (int k = 0; k <= 101; ++k) {
-            double purity = k <= 100 ? (double)k / 100.0 : c.quality_threshold_r2[m];
-            put_f32(host_clip_f((float)host_round2(purity - c.quality_threshold[m]), -1.0f, 1.0f));
+            // a container's purity is an np.float64 quotient (numpy's round); an EMPTY container's is the threshold, a
+            // Python float, and so is its difference (Python's round): env_super.py:212-227, 786-789
+            const double diff = k <= 100 ? host_round2((double)k / 100.0 - c.quality_threshold[m])
+                                         : host_round2_py(c.quality_threshold_r2[m] - c.quality_threshold[m]);
+            put_f32(host_clip_f((float)diff, -1.0f, 1.0f));
         }
     }
     P.off_timer0 = (int)image.size(); // env_super.py:354-356

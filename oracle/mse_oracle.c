@@ -12,6 +12,7 @@
 #include "mse_oracle.h"
 
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -208,6 +209,16 @@ double orc_round2(double x)
     return r / 100.0;
 }
 
+/* Python's round(float, 2): correctly rounded on the exact binary value, exact ties to even - what the reference gets
+ * where the operand is a plain Python float (a threshold read from config.yml), unlike round(np.float64, 2) above.
+ * glibc's printf rounds the exact value the same way. */
+double orc_round2_py(double x)
+{
+    char buf[64];
+    snprintf(buf, sizeof buf, "%.2f", x);
+    return strtod(buf, NULL);
+}
+
 /* int(round(np.float64)) : half to even */
 int64_t orc_rint_i64(double x) { return (int64_t)nearbyint(x); }
 
@@ -349,12 +360,10 @@ static void container_purity(const orc_env *e, double purity[4])
 {
     for (int m = 0; m < 4; ++m) {
         int64_t total = e->cont_true[m] + e->cont_false[m];
-        double p;
-        if (total > 0)
-            p = (double)e->cont_true[m] / (double)total;
-        else
-            p = e->cfg.quality_threshold[m];
-        purity[m] = orc_round2(p);
+        if (total > 0) /* an np.float64 quotient: numpy's round */
+            purity[m] = orc_round2((double)e->cont_true[m] / (double)total);
+        else           /* :786-789 the threshold itself, a Python float from config.yml: Python's round */
+            purity[m] = orc_round2_py(e->cfg.quality_threshold[m]);
     }
 }
 
@@ -370,9 +379,10 @@ static void sort_obs(const orc_env *e, float *o)
     for (int m = 0; m < 4; ++m) o[5 + m] = (float)e->acc_belt[m];
     double purity[4];
     container_purity(e, purity);
-    for (int m = 0; m < 4; ++m) {
+    for (int m = 0; m < 4; ++m) { /* :212-227: round(diff, 2) rounds as its operand's type does (see container_purity) */
         double diff = purity[m] - e->cfg.quality_threshold[m];
-        o[9 + m] = (float)orc_round2(diff);
+        int empty = e->cont_true[m] + e->cont_false[m] == 0;
+        o[9 + m] = (float)(empty ? orc_round2_py(diff) : orc_round2(diff));
     }
     for (int i = 0; i < 13; ++i) o[i] = clipf(o[i], -1.0f, 1.0f);
 }

@@ -48,6 +48,7 @@ int64_t  orc_pcg64_integers(orc_pcg64 *g, int64_t lo, int64_t hi_excl); /* Gener
 int      orc_pcg64_choice_p(orc_pcg64 *g, const double *p, int n);      /* Generator.choice(n,p) */
 int      orc_permutation12_first(uint64_t seed); /* first element of default_rng(seed).permutation([1,2]) */
 double   orc_round2(double x);                   /* round(np.float64, 2)                         */
+double   orc_round2_py(double x);                /* round(python float, 2): correctly rounded    */
 int64_t  orc_rint_i64(double x);                 /* int(round(np.float64))                       */
 
 /* ---- environment --------------------------------------------------------------------- */

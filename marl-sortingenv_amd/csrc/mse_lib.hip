@@ -166,6 +166,85 @@ __device__ __forceinline__ void stage_and_store(uint8_t *lds_base, int mask_offs
     __builtin_amdgcn_wave_barrier(); // the tile is rewritten by this wave only, after its own reads
 }
 
+// The same staging for the one-lane rollout kernel with HALF the LDS: a wave streams its 64 observation rows in two
+// passes of 32 rows through a 32-row tile (lanes 0-31 write theirs, all 64 lanes store; then lanes 32-63), the mask rows
+// (64 x A <= 32 x D x 4 bytes) in one pass through the same tile.  LDS per workgroup decides how many workgroups a CU
+// holds, and with one lane per env that is the number of waves per SIMD the transition's latencies hide under.
+template <int KIND>
+__device__ __forceinline__ void stage_and_store_halves(uint8_t *lds_base, const float *o, uint32_t mbits, float *gobs,
+                                                       uint8_t *gmask, int n_valid_block, int tid)
+{
+    constexpr int D = Dims<KIND>::D, A = Dims<KIND>::A;
+    static_assert(64 * A <= 32 * D * 4, "the mask tile must fit the half observation tile");
+    const int wave = tid >> 6, lane = tid & 63;
+    const int n_valid = min(max(n_valid_block - wave * 64, 0), 64);
+    float *ltile = reinterpret_cast<float *>(lds_base) + wave * 32 * D;
+    if (gobs != nullptr) {
+        float *g = gobs + wave * 64 * D;
+        constexpr int NQ = 32 * D / 4;                // 16-byte pieces of a half tile
+        constexpr int NR = (NQ + 63) / 64;
+        const bool fast = n_valid == 64 && (reinterpret_cast<uintptr_t>(g) & 15u) == 0 && (32 * D * 4) % 16 == 0;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            if ((lane >> 5) == half) {
+#pragma unroll
+                for (int j = 0; j < D; ++j) ltile[(lane & 31) * D + j] = o[j];
+            }
+            __builtin_amdgcn_wave_barrier();
+            float *gh = g + half * 32 * D;
+            if (fast) {
+                const float4 *src = reinterpret_cast<const float4 *>(ltile);
+                float4 buf[NR];
+#pragma unroll
+                for (int j = 0; j < NR; ++j) buf[j] = src[(lane + 64 * j) < NQ ? lane + 64 * j : 0];
+#pragma unroll
+                for (int j = 0; j < NR; ++j)
+                    if (lane + 64 * j < NQ) store_stream(reinterpret_cast<float4 *>(gh) + lane + 64 * j, buf[j]);
+            } else {
+                const int rows = min(max(n_valid - half * 32, 0), 32);
+                for (int q = lane; q < rows * D; q += 64) gh[q] = ltile[q];
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    if (gmask != nullptr) {
+        uint8_t *lmask = reinterpret_cast<uint8_t *>(ltile);
+        uint8_t *g = gmask + wave * 64 * A;
+        if (A % 2 == 0) {
+            uint16_t *row = reinterpret_cast<uint16_t *>(lmask + lane * A);
+#pragma unroll
+            for (int j = 0; j < A / 2; ++j)
+                row[j] = (uint16_t)(((mbits >> (2 * j)) & 1u) | (((mbits >> (2 * j + 1)) & 1u) << 8));
+        } else {
+#pragma unroll
+            for (int j = 0; j < A; ++j) lmask[lane * A + j] = (uint8_t)((mbits >> j) & 1u);
+        }
+        __builtin_amdgcn_wave_barrier();
+        constexpr int NQ = 64 * A / 16;
+        if (n_valid == 64 && (64 * A) % 16 == 0 && NQ <= 128 && (reinterpret_cast<uintptr_t>(g) & 15u) == 0) {
+            const uint4 *src = reinterpret_cast<const uint4 *>(lmask);
+            const uint4 b0 = src[lane < NQ ? lane : 0];
+            const uint4 b1 = src[(lane + 64) < NQ ? lane + 64 : 0];
+            if (lane < NQ) store_stream(reinterpret_cast<uint4 *>(g) + lane, b0);
+            if (NQ > 64 && lane + 64 < NQ) store_stream(reinterpret_cast<uint4 *>(g) + lane + 64, b1);
+        } else {
+            for (int q = lane; q < n_valid * A; q += 64) g[q] = lmask[q];
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// LDS of the one-lane rollout kernel: [half observation tiles, 32 rows per wave][bale ledger][tables up to the
+// jump tables, which only the three-role kernel reads]
+template <int KIND>
+struct RolloutLayout {
+    static constexpr int D = Dims<KIND>::D;
+    static constexpr int tile_bytes = (kBlock / 2 * D * 4 + 15) / 16 * 16;
+    static constexpr int bale_offset = tile_bytes;
+    static constexpr int bale_bytes = 5 * kBlock * 16;
+    static constexpr int table_offset = bale_offset + bale_bytes;
+};
+
 // auto-reset of a finished episode inside the step (reset(seed=None) semantics: streams continue)
 template <bool GEN = false>
 __device__ __forceinline__ void auto_reset_env(Env &e, const Params &P, const Tables &tb, const BaleRef &bales, int k[4])
@@ -300,8 +379,10 @@ __global__ __launch_bounds__(kBlock) void k_step(Params P, uint4 *__restrict__ p
                           mask_out ? mask_out + row0 * A : nullptr, n_valid, tid);
 }
 
+// Three workgroups per CU (42.6 KB of LDS each for Env_3): three waves per SIMD, so at most 168 VGPRs (the transition
+// itself needs ~125: k_step; left alone the compiler spends 214 here and halves... a third of the occupancy).
 template <int KIND, bool NOISE, bool LITERAL, bool GEN = false>
-__global__ __launch_bounds__(kBlock) void k_rollout(Params P, uint4 *__restrict__ planes,
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) void k_rollout(Params P, uint4 *__restrict__ planes,
                                                     const uint32_t *__restrict__ table_image, int k_steps,
                                                     uint64_t policy_seed, uint64_t policy_t0,
                                                     const int *__restrict__ sort_mode, uint32_t flags,
@@ -311,8 +392,8 @@ __global__ __launch_bounds__(kBlock) void k_rollout(Params P, uint4 *__restrict_
 {
     constexpr int D = Dims<KIND>::D, A = Dims<KIND>::A;
     uint8_t *lds = reinterpret_cast<uint8_t *>(mse_dyn_lds);
-    uint32_t *ltab = reinterpret_cast<uint32_t *>(lds + LdsLayout<KIND>::table_offset_rollout);
-    uint4 *lbale = reinterpret_cast<uint4 *>(lds + LdsLayout<KIND>::bale_offset);
+    uint32_t *ltab = reinterpret_cast<uint32_t *>(lds + RolloutLayout<KIND>::table_offset);
+    uint4 *lbale = reinterpret_cast<uint4 *>(lds + RolloutLayout<KIND>::bale_offset);
     const int tid = threadIdx.x;
     const long long row0 = (long long)blockIdx.x * kBlock;
     const long long i = row0 + tid; // i < n_pad always: the planes are padded to whole workgroups
@@ -326,7 +407,7 @@ __global__ __launch_bounds__(kBlock) void k_rollout(Params P, uint4 *__restrict_
 #pragma unroll
         for (int m = 0; m < 5; ++m) lbale[m * kBlock + tid] = planes[(long long)(PL_BALE0 + m) * P.n_pad + i];
     }
-    load_tables_to_lds(ltab, table_image, P.table_words, tid);
+    load_tables_to_lds(ltab, table_image, GEN ? P.table_words : P.off_jump, tid); // off_jump is a multiple of 4 words
     const Tables tb = tables_at(ltab, P);
 
     Env e;
@@ -361,8 +442,8 @@ __global__ __launch_bounds__(kBlock) void k_rollout(Params P, uint4 *__restrict_
             if (reward_out != nullptr) __builtin_nontemporal_store((float)r.reward, &reward_out[(long long)s * P.n + i]);
             if (done_out != nullptr) __builtin_nontemporal_store((uint8_t)r.done, &done_out[(long long)s * P.n + i]);
         }
-        stage_and_store<KIND>(lds, LdsLayout<KIND>::obs_bytes, o, mbits, obs_out ? obs_out + srow * D : nullptr,
-                              mask_out ? mask_out + srow * A : nullptr, n_valid, tid);
+        stage_and_store_halves<KIND>(lds, o, mbits, obs_out ? obs_out + srow * D : nullptr,
+                                     mask_out ? mask_out + srow * A : nullptr, n_valid, tid);
     }
     if (live) {
         store_env<KIND, NOISE>(e, planes, P, i, false);
@@ -1612,7 +1693,8 @@ static int build_tables(const mse_config &c, Params &P, std::vector<uint32_t> &i
         for (int m = 0; m < 4; ++m) cst[CST_BASE_ACC0 + m] = c.baseline_accuracy[m];
         for (int k = 0; k < CST_COUNT; ++k) put_f64(cst[k]);
     }
-    P.off_jump = (int)image.size(); // even: only 8-byte items since off_cst
+    while (image.size() & 3u) image.push_back(0u); // the one-lane rollout kernel copies [0, off_jump) in 16-byte pieces
+    P.off_jump = (int)image.size();
     {
         // LCG jump-ahead by 2^j steps: A = M^(2^j), G = 1 + M + ... + M^(2^j - 1)  (mod 2^128)
         typedef unsigned __int128 u128;
@@ -1672,7 +1754,7 @@ static size_t lds_bytes_step(const mse_env *h)
 template <int KIND>
 static size_t lds_bytes_rollout(const mse_env *h)
 {
-    return (size_t)LdsLayout<KIND>::table_offset_rollout + (size_t)h->P.table_words * 4u;
+    return (size_t)RolloutLayout<KIND>::table_offset + (size_t)(h->P.gen_mode ? h->P.table_words : h->P.off_jump) * 4u;
 }
 
 static inline dim3 grid_of(const mse_env *h) { return dim3((unsigned)(h->P.n_pad / kBlock)); }

@@ -1280,9 +1280,10 @@ struct Ledger {
 //   floor(n / S)                                       ->  integer division (exact: the quotient of two int32 as a
 //                                                          double is within 2^-52 of the true value, never across an integer)
 //   rem > S * bale_remainder_threshold                 ->  rem > P.rem_thr_units = floor(S * thr), same test on integers
-__device__ __forceinline__ void press_bale(uint4 *cell, const Params &P, int n, int q100)
+template <class BALES>
+__device__ __forceinline__ void press_bale(const BALES &bales, int m, const Params &P, int n, int q100)
 {
-    uint4 c = *cell;
+    uint4 c = bales.load(m);
     const uint32_t qi = bale_quality_int(P, q100);
     const uint32_t S = (uint32_t)P.balesize;
     int full_i, rem_i;
@@ -1314,7 +1315,7 @@ __device__ __forceinline__ void press_bale(uint4 *cell, const Params &P, int n, 
             c.w = qi;
         }
     }
-    *cell = c;
+    bales.store(m, c);
 }
 
 // where the bale ledger of this lane lives: global planes (single-step kernel) or an LDS copy
@@ -1322,12 +1323,31 @@ __device__ __forceinline__ void press_bale(uint4 *cell, const Params &P, int n, 
 struct BaleRef {
     uint4 *base;        // cell (m) at base[m * stride]
     long long stride;
-    __device__ __forceinline__ uint4 *cell(int m) const { return base + (long long)m * stride; }
+    __device__ __forceinline__ uint4 load(int m) const { return base[(long long)m * stride]; }
+    __device__ __forceinline__ void store(int m, const uint4 &c) const { base[(long long)m * stride] = c; }
+};
+// The same ledger in 12 bytes per cell, for kernels whose occupancy hangs on their LDS: words {count, sum,
+// last_size | last_q << 24}, word w of material m of env slot el at base[(3 m + w) * stride + el].  A bale's size stays
+// below 2^24 (an episode adds at most batch x 65 535 units to a container) and q is a percentage.
+struct BaleRefCompact {
+    uint32_t *base;     // already offset by the env slot
+    int stride;
+    __device__ __forceinline__ uint4 load(int m) const
+    {
+        const uint32_t w2 = base[(3 * m + 2) * stride];
+        return make_uint4(base[(3 * m) * stride], base[(3 * m + 1) * stride], w2 & 0xFFFFFFu, w2 >> 24);
+    }
+    __device__ __forceinline__ void store(int m, const uint4 &c) const
+    {
+        base[(3 * m) * stride] = c.x;
+        base[(3 * m + 1) * stride] = c.y;
+        base[(3 * m + 2) * stride] = (c.z & 0xFFFFFFu) | (c.w << 24);
+    }
 };
 
 // env_super.py:626-640 press_action_rules = check_press_status (:642-659) then use_press (:722-769)
-template <bool TRACE = false>
-__device__ __forceinline__ void press_action_rules(Env &e, const Params &P, int press_action, const BaleRef &bales,
+template <bool TRACE = false, class BALES = BaleRef>
+__device__ __forceinline__ void press_action_rules(Env &e, const Params &P, int press_action, const BALES &bales,
                                                    Ledger *lg = nullptr)
 {
     // check_press_status: both timers tick; a press that reaches 0 books its bale.  A finishing press is rare per
@@ -1349,9 +1369,9 @@ __device__ __forceinline__ void press_action_rules(Env &e, const Params &P, int 
             }
         }
         if (P.track_bales)
-            press_bale(bales.cell(first ? e.pmat[1] : e.pmat[0]), P, first ? e.pn[1] : e.pn[0], first ? e.q100[1] : e.q100[0]);
+            press_bale(bales, first ? e.pmat[1] : e.pmat[0], P, first ? e.pn[1] : e.pn[0], first ? e.q100[1] : e.q100[0]);
         if (__builtin_expect(fin0 && fin1, 0)) { // press 0 was booked above (reference order: press 1, then 2)
-            if (P.track_bales) press_bale(bales.cell(e.pmat[1]), P, e.pn[1], e.q100[1]);
+            if (P.track_bales) press_bale(bales, e.pmat[1], P, e.pn[1], e.q100[1]);
         }
         if (fin0) {
             e.pmat[0] = 0xFF;
@@ -1613,10 +1633,11 @@ __device__ __forceinline__ void reset_episode_state(Env &e, const double *cst)
     e.step = 0;
 }
 
-__device__ __forceinline__ void clear_bales(const BaleRef &bales)
+template <class BALES>
+__device__ __forceinline__ void clear_bales(const BALES &bales)
 {
 #pragma unroll
-    for (int m = 0; m < 5; ++m) *bales.cell(m) = make_uint4(0, 0, 0, 0);
+    for (int m = 0; m < 5; ++m) bales.store(m, make_uint4(0, 0, 0, 0));
 }
 
 
@@ -1658,9 +1679,9 @@ __device__ __forceinline__ PenaltyClass classify_levels(const int lvl[5], const 
 
 // env_1_sort.py:97-154 / env_2_press.py:88-165 / env_monolith.py:109-284 up to (not including) the reward
 // and observation, plus the state side effects of calculate_press_reward and the step counter.
-template <int KIND, bool NOISE, bool LITERAL, class RNG, bool TRACE = false, bool GEN = false>
+template <int KIND, bool NOISE, bool LITERAL, class RNG, bool TRACE = false, bool GEN = false, class BALES = BaleRef>
 __device__ __forceinline__ void env_dynamics(Env &e, RNG &rng, const Params &P, const Tables &tb, int action,
-                                             int sort_mode_in, uint32_t flags, const BaleRef &bales, Snap &sn,
+                                             int sort_mode_in, uint32_t flags, const BALES &bales, Snap &sn,
                                              Ledger *lg = nullptr)
 {
     const bool unmasked = (flags & 1u) != 0;
@@ -1725,7 +1746,7 @@ __device__ __forceinline__ void env_dynamics(Env &e, RNG &rng, const Params &P, 
             }
         }
     }
-    if (run_press_rules) press_action_rules<TRACE>(e, P, press_action, bales, lg);
+    if (run_press_rules) press_action_rules<TRACE, BALES>(e, P, press_action, bales, lg);
     MSE_TL(e.tl, 3);
 
     // snapshot for the observer
@@ -1915,14 +1936,14 @@ __device__ __forceinline__ void snap_of_reset(Snap &sn, const double *cst)
 }
 
 // one env transition in one lane
-template <int KIND, bool NOISE, bool LITERAL, bool TRACE = false, bool GEN = false>
+template <int KIND, bool NOISE, bool LITERAL, bool TRACE = false, bool GEN = false, class BALES = BaleRef>
 __device__ __forceinline__ StepResult env_step(Env &e, const Params &P, const Tables &tb, int action, int sort_mode_in,
-                                               uint32_t flags, const BaleRef &bales, int k[4], float *o,
+                                               uint32_t flags, const BALES &bales, int k[4], float *o,
                                                Ledger *lg = nullptr)
 {
     Snap sn;
     RngLocal rng{e.rng};
-    env_dynamics<KIND, NOISE, LITERAL, RngLocal, TRACE, GEN>(e, rng, P, tb, action, sort_mode_in, flags, bales, sn, lg);
+    env_dynamics<KIND, NOISE, LITERAL, RngLocal, TRACE, GEN, BALES>(e, rng, P, tb, action, sort_mode_in, flags, bales, sn, lg);
     return env_observe<KIND, NOISE, GEN>(sn, P, tb, k, o);
 }
 

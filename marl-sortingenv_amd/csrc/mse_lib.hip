@@ -50,6 +50,8 @@ __device__ __forceinline__ void lds_barrier_all()
 template <int THREADS, int U>
 struct TableCopy {
     uint4 x[U];
+    // loads are unconditional at a clamped index (a conditional load makes the compiler keep x[] in scratch memory:
+    // load, wait, scratch store, scratch load, wait, LDS write - two memory round trips in the launch prologue)
     __device__ __forceinline__ void issue(const uint32_t *__restrict__ src, int words, int t)
     {
         const uint4 *s4 = reinterpret_cast<const uint4 *>(src);
@@ -57,7 +59,7 @@ struct TableCopy {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int idx = u * THREADS + t;
-            if (idx < n4) x[u] = s4[idx];
+            x[u] = s4[idx < n4 ? idx : n4 - 1];
         }
     }
     __device__ __forceinline__ void commit(uint32_t *dst, const uint32_t *__restrict__ src, int words, int t) const
@@ -234,20 +236,20 @@ __device__ __forceinline__ void stage_and_store_halves(uint8_t *lds_base, const 
     }
 }
 
-// LDS of the one-lane rollout kernel: [half observation tiles, 32 rows per wave][bale ledger][tables up to the
-// jump tables, which only the three-role kernel reads]
+// LDS of the one-lane rollout kernel: [half observation tiles, 32 rows per wave][bale ledger, 12-byte cells][tables up
+// to the jump tables, which only the three-role kernel reads]: 38 KB for Env_3, four workgroups per CU
 template <int KIND>
 struct RolloutLayout {
     static constexpr int D = Dims<KIND>::D;
     static constexpr int tile_bytes = (kBlock / 2 * D * 4 + 15) / 16 * 16;
     static constexpr int bale_offset = tile_bytes;
-    static constexpr int bale_bytes = 5 * kBlock * 16;
+    static constexpr int bale_bytes = 5 * 3 * kBlock * 4; // BaleRefCompact: 12 bytes per cell
     static constexpr int table_offset = bale_offset + bale_bytes;
 };
 
 // auto-reset of a finished episode inside the step (reset(seed=None) semantics: streams continue)
-template <bool GEN = false>
-__device__ __forceinline__ void auto_reset_env(Env &e, const Params &P, const Tables &tb, const BaleRef &bales, int k[4])
+template <bool GEN = false, class BALES = BaleRef>
+__device__ __forceinline__ void auto_reset_env(Env &e, const Params &P, const Tables &tb, const BALES &bales, int k[4])
 {
     e.gen2 = unseeded_gen2(e);
     if (GEN) unseeded_generator(e);
@@ -379,8 +381,10 @@ __global__ __launch_bounds__(kBlock) void k_step(Params P, uint4 *__restrict__ p
                           mask_out ? mask_out + row0 * A : nullptr, n_valid, tid);
 }
 
-// Three workgroups per CU (42.6 KB of LDS each for Env_3): three waves per SIMD, so at most 168 VGPRs (the transition
-// itself needs ~125: k_step; left alone the compiler spends 214 here and halves... a third of the occupancy).
+// Three workgroups per CU: three waves per SIMD, so at most 168 VGPRs (left alone the compiler spends 214 here: two).
+// The LDS image (38 KB for Env_3) would let a fourth in, but a 128-register build spills 20 dwords inside the step loop
+// and measured slower at every size (17.6 / 21.4 / 23.3 / 24.8 G against 20.3 / 23.4 / 23.3 / 26.8 at 131 072 / 196 608 /
+// 262 144 / 1 048 576 envs).
 template <int KIND, bool NOISE, bool LITERAL, bool GEN = false>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) void k_rollout(Params P, uint4 *__restrict__ planes,
                                                     const uint32_t *__restrict__ table_image, int k_steps,
@@ -393,7 +397,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
     constexpr int D = Dims<KIND>::D, A = Dims<KIND>::A;
     uint8_t *lds = reinterpret_cast<uint8_t *>(mse_dyn_lds);
     uint32_t *ltab = reinterpret_cast<uint32_t *>(lds + RolloutLayout<KIND>::table_offset);
-    uint4 *lbale = reinterpret_cast<uint4 *>(lds + RolloutLayout<KIND>::bale_offset);
+    uint32_t *lbale = reinterpret_cast<uint32_t *>(lds + RolloutLayout<KIND>::bale_offset);
     const int tid = threadIdx.x;
     const long long row0 = (long long)blockIdx.x * kBlock;
     const long long i = row0 + tid; // i < n_pad always: the planes are padded to whole workgroups
@@ -402,10 +406,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
     const int n_valid = rem >= kBlock ? kBlock : (rem > 0 ? (int)rem : 0);
 
     // the bale ledger of this workgroup's envs stays in LDS for the whole launch
-    const BaleRef bales{lbale + tid, kBlock};
+    const BaleRefCompact bales{lbale + tid, kBlock};
     if (P.track_bales) {
 #pragma unroll
-        for (int m = 0; m < 5; ++m) lbale[m * kBlock + tid] = planes[(long long)(PL_BALE0 + m) * P.n_pad + i];
+        for (int m = 0; m < 5; ++m) bales.store(m, planes[(long long)(PL_BALE0 + m) * P.n_pad + i]);
     }
     load_tables_to_lds(ltab, table_image, GEN ? P.table_words : P.off_jump, tid); // off_jump is a multiple of 4 words
     const Tables tb = tables_at(ltab, P);
@@ -419,21 +423,21 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
     }
     // every load has landed before the step loop: inside it there are only stores, which nothing waits for
     __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
-    float o[D];
-#pragma unroll
-    for (int j = 0; j < D; ++j) o[j] = 0.0f;
     uint32_t cur_mask = live ? action_mask_bits<KIND>(e, P) : 1u;
     const uint32_t pkey = mse_policy_key(policy_seed, (uint64_t)(P.index_offset + i));
 
     for (int s = 0; s < k_steps; ++s) {
+        float o[D]; // per step: nothing of the observation lives across the loop's back edge
+#pragma unroll
+        for (int j = 0; j < D; ++j) o[j] = 0.0f;
         uint32_t mbits = 0;
         const long long srow = (long long)s * P.n + row0;
         if (live) {
             int a = policy_action<KIND, GEN>(e, cur_mask, tb, flags, pkey, policy_t0 + (uint64_t)s);
             int k[4];
-            StepResult r = env_step<KIND, NOISE, LITERAL, false, GEN>(e, P, tb, a, sm, flags, bales, k, o);
+            StepResult r = env_step<KIND, NOISE, LITERAL, false, GEN, BaleRefCompact>(e, P, tb, a, sm, flags, bales, k, o);
             if (__builtin_expect(r.done != 0, 0)) { // every env of a batch finishes its episode on the same step: rare, wave-uniform
-                auto_reset_env<GEN>(e, P, tb, bales, k);
+                auto_reset_env<GEN, BaleRefCompact>(e, P, tb, bales, k);
                 env_obs<KIND, GEN>(e, P, tb, k, o);
             }
             mbits = action_mask_bits<KIND>(e, P);
@@ -451,7 +455,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
     }
     if (P.track_bales) {
 #pragma unroll
-        for (int m = 0; m < 5; ++m) planes[(long long)(PL_BALE0 + m) * P.n_pad + i] = lbale[m * kBlock + tid];
+        for (int m = 0; m < 5; ++m) planes[(long long)(PL_BALE0 + m) * P.n_pad + i] = bales.load(m);
     }
 }
 

@@ -1530,6 +1530,7 @@ struct mse_env {
     // opt-in trace of one env (mse_trace_begin): records_dev f64[capacity][MSE_TRACE_COLS], caller-owned
     double *trace_rec;
     int64_t trace_env, trace_capacity, trace_count;
+    int cus;                     // compute units of the device
 };
 
 static thread_local std::string g_last_error;
@@ -1858,11 +1859,7 @@ static int launch_rollout_policy(mse_env *h, const mse_policy *pol, const mse_po
     // Shape: eight waves per workgroup, two per SIMD.  While 32-env waves leave every CU at most one workgroup's worth
     // (n <= 256 envs x CUs) a wave owns 32 envs - at that size 64-env waves would run one per SIMD, at a vector
     // instruction per ~5 cycles; beyond, 64 envs.  The exact-f32 form only exists in the 64-env shape.
-    int cus = 256;
-    {
-        hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, h->device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
-    }
+    const int cus = h->cus; // queried once at create: hipGetDeviceProperties is far too slow for a launch path
     const bool f16 = pol->use_f16();
     const int tiles = (f16 && h->P.n <= (long long)256 * cus) ? 1 : 2;
     // (the exact-f32 form below that size: four 64-env waves per workgroup, so that every CU gets one)
@@ -2058,6 +2055,7 @@ int mse_create_indexed(mse_env **out, const mse_config *cfg, int64_t n_envs, int
         if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0)
             cus = prop.multiProcessorCount;
     }
+    h->cus = cus;
     h->pipelined = cfg->rollout_pipeline == 1 || cfg->rollout_pipeline == 3 ||
                    (cfg->rollout_pipeline == 0 && n_envs <= (int64_t)kPoEnvs * cus);
     if (P.gen_mode) { // general generator mode: the multi-role kernels carry stage ids, not counts

@@ -55,3 +55,28 @@ def test_wide_window_rollout_kernels_equal_shipped_literal(kind, pipeline):
     for x, y in zip(a.get_state(), b.get_state()):
         assert torch.equal(x, y)
     assert a.error_count() == 0
+
+
+@pytest.mark.parametrize("kind,n", [("mono", 3000), ("press", 70300)])
+def test_wide_window_fused_policy_rollout_equals_shipped(kind, n):
+    """mse_rollout_policy steps the env with the windowed decision too: the wide-window build (fallback about
+    every third step, both tile shapes) must collect what the shipped build collects, bit for bit."""
+    import torch
+
+    import marl_sortingenv_amd as M
+    from tests.test_gpu_policy import _weights
+
+    lib = _wide_lib()
+    K = 20
+    kw = dict(kind=kind, num_envs=n, device=0, base_seed=23, max_steps=15, noise_sorting=0.05, balesize=200)
+    a, b = M.BatchedSortingEnv(library=lib, **kw), M.BatchedSortingEnv(**kw)
+    w = _weights(a.obs_dim, a.num_actions, seed=9)
+    fa = M.FusedPolicyRollout(a, M.MlpPolicy(a.obs_dim, a.num_actions, w, device=0, library=lib), K, seed=4)
+    fb = M.FusedPolicyRollout(b, M.MlpPolicy(b.obs_dim, b.num_actions, w, device=0), K, seed=4)
+    for it in range(2):
+        x, y = fa.collect(), fb.collect()
+        for key in x:
+            assert torch.equal(x[key], y[key]), (it, key)
+    for sa, sb in zip(a.get_state(), b.get_state()):
+        assert torch.equal(sa, sb)
+    assert a.error_count() == 0

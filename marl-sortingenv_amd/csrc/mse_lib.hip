@@ -1032,26 +1032,30 @@ __global__ __launch_bounds__(512) void k_rollout_policy(Params P, uint4 *__restr
     uint8_t *lwave = lds + kWeightBytes + table_bytes + wave * L::wave_bytes;
     uint4 *lbale = reinterpret_cast<uint4 *>(lwave + L::tile_bytes);
     const long long wave_row0 = ((long long)blockIdx.x * n_waves + wave) * ENVS;
-    const bool wave_active = wave_row0 < P.n_pad; // the planes are padded to 256 envs: the last workgroup may overhang
-    const bool env_lane = lane < ENVS;            // TILES = 1: lanes 32-63 hold no env
-    const long long i = (wave_active && env_lane) ? wave_row0 + lane : 0;
-    const bool live = wave_active && env_lane && i < P.n;
     long long rem = P.n - wave_row0;
     const int n_valid = rem >= ENVS ? ENVS : (rem > 0 ? (int)rem : 0);
+    const bool wave_active = n_valid > 0;
+    // Every lane of an active wave steps an env, so that the step loop has no per-lane "is there an env here" region
+    // (the compiler kept two copies of the env's ~90 registers around one and moved them back and forth every step):
+    // TILES = 1: lanes 32-63 mirror lanes 0-31; lanes past the batch's end mirror its last env.  Mirrors compute what
+    // their original computes and store nothing.
+    const int src_lane = TILES == 1 ? (lane & 31) : lane;
+    const bool live = wave_active && lane < ENVS && wave_row0 + lane < P.n;
+    const long long i = wave_active ? (wave_row0 + src_lane < P.n ? wave_row0 + src_lane : P.n - 1) : 0;
 
     msep_copy_image(lw, weight_blob, F16X3, tid, blockDim.x);
     if (SORTPOL) msep_copy_image(lw + msep::kLdsFloats, sort_weight_blob, F16X3, tid, blockDim.x);
     for (int w = tid; w < P.table_words / 4; w += blockDim.x)
         reinterpret_cast<uint4 *>(ltab)[w] = reinterpret_cast<const uint4 *>(table_image)[w];
-    const BaleRef bales{lbale + (env_lane ? lane : 0), ENVS};
-    if (P.track_bales && wave_active && env_lane) {
+    const BaleRef bales{lbale + src_lane, ENVS};
+    if (P.track_bales && wave_active) {
 #pragma unroll
-        for (int m = 0; m < 5; ++m) lbale[m * ENVS + lane] = planes[(long long)(PL_BALE0 + m) * P.n_pad + i];
+        for (int m = 0; m < 5; ++m) lbale[m * ENVS + src_lane] = planes[(long long)(PL_BALE0 + m) * P.n_pad + i];
     }
     Env e;
     int sm = -1;
-    load_env<KIND, NOISE>(e, planes, P, i); // padded planes: safe for every lane of an active wave (idle lanes read env 0)
-    if (KIND == 2 && sort_mode != nullptr && live) sm = sort_mode[i];
+    load_env<KIND, NOISE>(e, planes, P, i);
+    if (KIND == 2 && sort_mode != nullptr) sm = sort_mode[i];
     __syncthreads();
     if (!wave_active) return;
     __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): nothing but stores inside the step loop
@@ -1062,13 +1066,10 @@ __global__ __launch_bounds__(512) void k_rollout_policy(Params P, uint4 *__restr
     float o[32];
 #pragma unroll
     for (int j = 0; j < 32; ++j) o[j] = 0.0f;
-    uint32_t mbits = 0;
-    int kcur[4] = {101, 101, 101, 101}; // container purities of the current state (the sorting agent's view needs them)
-    if (live) {
-        container_purity_k(e, kcur);
-        env_obs<KIND>(e, P, tb, kcur, o);
-        mbits = action_mask_bits<KIND>(e, P);
-    }
+    int kcur[4]; // container purities of the current state (the sorting agent's view needs them)
+    container_purity_k(e, kcur);
+    env_obs<KIND>(e, P, tb, kcur, o);
+    uint32_t mbits = action_mask_bits<KIND>(e, P);
     msep::lds_f4 wl_sort = (msep::lds_f4)(__attribute__((address_space(3))) float *)(lw + msep::kLdsFloats);
     // policy stream keys of the env(s) this lane serves as an MFMA column: tile t = envs 32 t .. 32 t + 31 of the wave
     const int h = lane >> 5, col = lane & 31;
@@ -1080,38 +1081,43 @@ __global__ __launch_bounds__(512) void k_rollout_policy(Params P, uint4 *__restr
         const uint32_t t = env_bits >> (4 * h);
         return (t & 0xFu) | ((t >> 4) & 0xF0u) | ((t >> 8) & 0xF00u) | ((t >> 12) & 0xF000u);
     };
-
-    int last_done = 0;
-    for (int s = 0; s <= k_steps; ++s) {
-        __builtin_amdgcn_s_setprio(TILES == 2 ? 3 : 0); // policy phase (see below)
-        const bool tail = s == k_steps; // one more forward after the last step: the bootstrap value of the final state
-        const long long srow = (long long)s * P.n + wave_row0;
-        if (!tail) {
-            // the row the action is taken from (MaskableRolloutBuffer: observations, action_masks, episode_starts)
-            if (obs_out != nullptr) wave_store_rows_f32<D, ENVS>(reinterpret_cast<float *>(lwave), o, obs_out + srow * D, n_valid, lane);
-            if (mask_out != nullptr) wave_store_rows_mask<A, ENVS>(lwave, mbits, mask_out + srow * A, n_valid, lane);
-            if (live && start_out != nullptr)
-                __builtin_nontemporal_store((uint8_t)(e.step == 0 ? 1 : 0), &start_out[(long long)s * P.n + i]);
-        }
-        // ---- policy.  swap(o[2q], o[2q+1]) = {tile 0's k-step q operand, tile 1's}: lanes 32-63 of tile 0 get the
-        // odd entries of the envs in lanes 0-31, lanes 0-31 of tile 1 the even entries of the envs in lanes 32-63
-        float x[2][16];
+    // swap(o[2q], o[2q+1]) = {tile 0's k-step q operand, tile 1's}: lanes 32-63 of tile 0 get the odd entries of the
+    // envs in lanes 0-31, lanes 0-31 of tile 1 the even entries of the envs in lanes 32-63
+    auto operands_of = [&](const float *ob, float (*x)[16]) {
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
-            auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(o[2 * q]), __float_as_uint(o[2 * q + 1]), false, false);
+            auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(ob[2 * q]), __float_as_uint(ob[2 * q + 1]), false, false);
             x[0][q] = __uint_as_float(r[0]);
             x[1][q] = __uint_as_float(r[1]);
         }
+    };
+
+    int last_done = 0;
+#ifdef MSE_TIMELINE
+    Timeline ptl;
+    ptl.start();
+#endif
+    for (int s = 0; s < k_steps; ++s) {
+        __builtin_amdgcn_s_setprio(TILES == 2 ? 3 : 0); // policy phase (see below)
+        const long long srow = (long long)s * P.n + wave_row0;
+        // the row the action is taken from (MaskableRolloutBuffer: observations, action_masks, episode_starts)
+        if (obs_out != nullptr) wave_store_rows_f32<D, ENVS>(reinterpret_cast<float *>(lwave), o, obs_out + srow * D, n_valid, lane);
+        if (mask_out != nullptr) wave_store_rows_mask<A, ENVS>(lwave, mbits, mask_out + srow * A, n_valid, lane);
+        if (live && start_out != nullptr)
+            __builtin_nontemporal_store((uint8_t)(e.step == 0 ? 1 : 0), &start_out[(long long)s * P.n + i]);
+        MSE_TLB(ptl, 0); // row stores
+        // ---- policy
+        float x[2][16];
+        operands_of(o, x);
         // without masking (plain PPO on the unmasked env) the policy samples from the whole action space and the
         // step sanitises; the recorded mask row is action_masks() either way
         uint32_t mb0, mb1;
         msep::both_halves_u32((flags & MSE_STEP_UNMASKED) ? ((1u << A) - 1u) : mbits, mb0, mb1);
         const uint64_t t = policy_t0 + (uint64_t)s;
-        const bool det = deterministic != 0 || tail;
         const uint32_t legal[2] = {legal_of(mb0), legal_of(mb1)};
         const uint32_t words[2] = {mse_policy_word(key0, t), mse_policy_word(key1, t)};
         msep::TileOut p[2];
-        msep::policy_tiles<NR, F16X3, TILES>(wl, lane, x, legal, det, words, nullptr, p);
+        msep::policy_tiles<NR, F16X3, TILES>(wl, lane, x, legal, deterministic != 0, words, nullptr, p);
         int a = p[0].action;
         float logp = p[0].logp, value = p[0].value;
         if (TILES == 2) { // lane l is env l: tile l >> 5, column l & 31 (results are valid in both halves)
@@ -1119,11 +1125,7 @@ __global__ __launch_bounds__(512) void k_rollout_policy(Params P, uint4 *__restr
             logp = h ? p[1].logp : logp;
             value = h ? p[1].value : value;
         }
-        if (tail) {
-            if (live && last_value_out != nullptr) last_value_out[i] = value;
-            if (live && last_done_out != nullptr) last_done_out[i] = (uint8_t)last_done;
-            break;
-        }
+        MSE_TLB(ptl, 1); // policy forward
         // Phase priorities: the two waves of a SIMD fall into step with each other (both in the policy, both in the
         // dynamics) and then compete for the same pipe; letting one phase win the issue arbitration pulls them apart so
         // that one wave's MFMA chains run under the other's dynamics.  Which phase should win was measured on the box
@@ -1136,43 +1138,49 @@ __global__ __launch_bounds__(512) void k_rollout_policy(Params P, uint4 *__restr
             float so[32];
 #pragma unroll
             for (int j = 0; j < 32; ++j) so[j] = 0.0f;
-            if (live) {
+            {
                 Env ec = e;
                 update_environment<false>(ec, P);
                 sort_obs<false>(ec, P, tb, kcur, so);
             }
             float sx[2][16];
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(so[2 * q]), __float_as_uint(so[2 * q + 1]), false, false);
-                sx[0][q] = __uint_as_float(r[0]);
-                sx[1][q] = __uint_as_float(r[1]);
-            }
+            operands_of(so, sx);
             int sa[2];
             msep::actor_argmax2_tiles<F16X3, TILES>(wl_sort, lane, sx, sa);
             sm = (TILES == 2 && h) ? sa[1] : sa[0];
         }
+        MSE_TLB(ptl, 2); // sorting agent
         // ---- the env transition under that action
+        StepResult r = env_step<KIND, NOISE, false>(e, P, tb, a, sm, flags, bales, kcur, o);
+        MSE_TLB(ptl, 3); // env transition
+        if (__builtin_expect(r.done != 0, 0)) {
+            auto_reset_env(e, P, tb, bales, kcur);
+            env_obs<KIND>(e, P, tb, kcur, o);
+        }
+        mbits = action_mask_bits<KIND>(e, P);
+        last_done = r.done;
         if (live) {
-            int k[4];
-            StepResult r = env_step<KIND, NOISE, false>(e, P, tb, a, sm, flags, bales, k, o);
-            if (__builtin_expect(r.done != 0, 0)) {
-                auto_reset_env(e, P, tb, bales, k);
-                env_obs<KIND>(e, P, tb, k, o);
-            }
-#pragma unroll
-            for (int m = 0; m < 4; ++m) kcur[m] = k[m];
-            mbits = action_mask_bits<KIND>(e, P);
-            last_done = r.done;
             const long long at = (long long)s * P.n + i;
             if (actions_out != nullptr) __builtin_nontemporal_store(a, &actions_out[at]);
             if (logp_out != nullptr) __builtin_nontemporal_store(logp, &logp_out[at]);
             if (value_out != nullptr) __builtin_nontemporal_store(value, &value_out[at]);
             if (reward_out != nullptr) __builtin_nontemporal_store((float)r.reward, &reward_out[at]);
         }
+        MSE_TLB(ptl, 4); // auto-reset, mask, per-env stores
     }
+#ifdef MSE_TIMELINE
+    ptl.flush(0);
+#endif
+    // the bootstrap value of the state the rollout ends in: the critic alone
+    if (last_value_out != nullptr) {
+        float x[2][16], v[2];
+        operands_of(o, x);
+        msep::value_tiles<F16X3, TILES>(wl, lane, x, v);
+        if (live) last_value_out[i] = (TILES == 2 && h) ? v[1] : v[0];
+    }
+    if (live && last_done_out != nullptr) last_done_out[i] = (uint8_t)last_done;
     if (live) store_env<KIND, NOISE>(e, planes, P, i, false);
-    if (P.track_bales && env_lane) {
+    if (P.track_bales && live) {
 #pragma unroll
         for (int m = 0; m < 5; ++m) planes[(long long)(PL_BALE0 + m) * P.n_pad + i] = lbale[m * ENVS + lane];
     }

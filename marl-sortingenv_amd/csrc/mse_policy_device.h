@@ -404,6 +404,29 @@ __device__ __forceinline__ void actor_argmax2_tiles(lds_f4 wl, int lane, const f
     }
 }
 
+// The critic alone for T tiles: the bootstrap value of the state a rollout ends in.  Same layers, same bits as
+// policy_tiles (a network's operations do not depend on what runs beside them).
+template <bool F16X3, int T>
+__device__ __forceinline__ void value_tiles(lds_f4 wl, int lane, const float (*x)[16], float *value)
+{
+    const int h = lane >> 5;
+    Operands<F16X3, T> xin, op;
+#pragma unroll
+    for (int t = 0; t < T; ++t) xin.set(t, x[t]);
+    float hid[16];
+    f32x16 acc[T], acc2[T];
+    apply_layer<T>(wl, lane, h, 3, xin, acc);
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) hid[r] = sigmoid2(acc[t][r]);
+        op.set(t, hid);
+    }
+    apply_layer<T>(wl, lane, h, 4, op, acc2);
+#pragma unroll
+    for (int t = 0; t < T; ++t) value[t] = value_tile(wl, h, acc2[t]);
+}
+
 // one tile (the standalone forward)
 template <int NR, bool F16X3>
 __device__ __forceinline__ TileOut policy_tile(lds_f4 wl, int lane, const float *x, uint32_t legal, bool deterministic,

@@ -307,9 +307,9 @@ def main():
         }
         if collector is not None and per_launch_ms:
             # the policy network's share: 10 240 flop per env and forward (5 layers of 32 x 32 x 2), one forward per
-            # step plus the bootstrap forward per launch; in the f16x3 form each product costs three f16 MFMAs
-            fwd = n * (steps_per_launch_avg + 1)
-            f32_equiv = 10240.0 * fwd / (per_launch_ms * 1e-3) / 1e12
+            # step plus the critic's two layers (4 096 flop) for the bootstrap value per launch; in the f16x3 form each
+            # product costs three f16 MFMAs
+            f32_equiv = n * (10240.0 * steps_per_launch_avg + 4096.0) / (per_launch_ms * 1e-3) / 1e12
             split = collector.policy.precision == "f16x3"
             out["roofline"]["mfma"] = {
                 "form": collector.policy.precision, "f32_equivalent_tflops": f32_equiv,

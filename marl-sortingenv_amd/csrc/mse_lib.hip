@@ -100,6 +100,25 @@ __device__ __forceinline__ void store_stream(uint4 *p, const uint4 &v)
     __builtin_nontemporal_store(x, reinterpret_cast<nt_u32x4 *>(p));
 }
 
+// A row of A action-mask bytes (A even) from the mask bits, to a 2-byte aligned row: four bytes per dword by one
+// 24-bit multiply (x * 0x204081 puts bit k of a nibble at bit 7 k + k; the mask keeps bits 0, 8, 16, 24), a trailing
+// pair as 16 bits.  The compiler merges the stores (22 bytes: 16 + 4 + 2).  Used by the learned-policy kernel only: in the
+// three-role kernel's observer the same 18 instructions measured 1-2 % slower end to end than the compiler's 45 bit operations
+// for the pairwise form below (same-box A/B), so stage_and_store keeps that.
+typedef uint32_t u32_align2 __attribute__((aligned(2)));
+template <int A, class P16>
+__device__ __forceinline__ void write_mask_row(P16 *row16, uint32_t mbits)
+{
+    static_assert(A % 2 == 0, "even rows only");
+#pragma unroll
+    for (int j = 0; j < A / 4; ++j) {
+        const uint32_t four = __umul24((mbits >> (4 * j)) & 0xFu, 0x00204081u) & 0x01010101u;
+        row16[2 * j] = (uint16_t)four;
+        row16[2 * j + 1] = (uint16_t)(four >> 16);
+    }
+    if (A % 4 == 2) row16[A / 2 - 1] = (uint16_t)(__umul24((mbits >> (A - 2)) & 0x3u, 0x00204081u) & 0x0101u);
+}
+
 // Each WAVE stages the 64 rows of its own lanes and streams them out itself: the rows of one wave are a
 // contiguous, 16-byte aligned run of the output (64 x 116 B for obs), and the LDS executes one wave's
 // instructions in order, so no workgroup barrier is needed (the first profile showed 36 % of wave time
@@ -959,12 +978,24 @@ struct PolLayout {
 
 // A wave's ROWS observation rows (D floats each, one per lane) / mask rows through its private LDS tile to global
 // memory as 16-byte pieces; ROWS = 32 | 64.  Same scheme as stage_and_store, for a wave-sized tile.
+// The lane's row of a wave tile as an LDS address the compiler cannot see through: left alone it keeps the tile's
+// constant offset out of the base register and, ds_write2's offsets being 8 bits, re-adds it before every store.
+typedef __attribute__((address_space(3))) float lds_f32;
+typedef __attribute__((address_space(3))) uint16_t lds_u16;
+__device__ __forceinline__ uint32_t lds_row_address(const void *row)
+{
+    uint32_t a = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)row;
+    asm volatile("" : "+v"(a));
+    return a;
+}
+
 template <int D, int ROWS>
-__device__ __forceinline__ void wave_store_rows_f32(float *ltile, const float *o, float *g, int n_valid, int lane)
+__device__ __forceinline__ void wave_store_rows_f32(float *ltile, uint32_t lrow, const float *o, float *g, int n_valid, int lane)
 {
     if (lane < ROWS) {
+        lds_f32 *row = (lds_f32 *)(uintptr_t)lrow; // = ltile + lane * D
 #pragma unroll
-        for (int j = 0; j < D; ++j) ltile[lane * D + j] = o[j];
+        for (int j = 0; j < D; ++j) row[j] = o[j];
     }
     __builtin_amdgcn_wave_barrier();
     constexpr int NQ = ROWS * D / 4; // 16-byte pieces of a full tile
@@ -984,11 +1015,15 @@ __device__ __forceinline__ void wave_store_rows_f32(float *ltile, const float *o
     __builtin_amdgcn_wave_barrier();
 }
 template <int A, int ROWS>
-__device__ __forceinline__ void wave_store_rows_mask(uint8_t *ltile, uint32_t mbits, uint8_t *g, int n_valid, int lane)
+__device__ __forceinline__ void wave_store_rows_mask(uint8_t *ltile, uint32_t lrow, uint32_t mbits, uint8_t *g, int n_valid, int lane)
 {
     if (lane < ROWS) {
+        if (A % 2 == 0) { // even row length: two mask bytes per 16-bit LDS store (the compiler merges them further)
+            if constexpr (A % 2 == 0) write_mask_row<A>((lds_u16 *)(uintptr_t)lrow, mbits); // lrow = ltile + lane * A
+        } else {
 #pragma unroll
-        for (int j = 0; j < A; ++j) ltile[lane * A + j] = (uint8_t)((mbits >> j) & 1u);
+            for (int j = 0; j < A; ++j) ltile[lane * A + j] = (uint8_t)((mbits >> j) & 1u);
+        }
     }
     __builtin_amdgcn_wave_barrier();
     constexpr int NQ = ROWS * A / 16;
@@ -1092,6 +1127,8 @@ __global__ __launch_bounds__(512) void k_rollout_policy(Params P, uint4 *__restr
         }
     };
 
+    const uint32_t lrow_obs = lds_row_address(reinterpret_cast<float *>(lwave) + src_lane * D);
+    const uint32_t lrow_mask = lds_row_address(lwave + src_lane * A);
     int last_done = 0;
 #ifdef MSE_TIMELINE
     Timeline ptl;
@@ -1101,8 +1138,8 @@ __global__ __launch_bounds__(512) void k_rollout_policy(Params P, uint4 *__restr
         __builtin_amdgcn_s_setprio(TILES == 2 ? 3 : 0); // policy phase (see below)
         const long long srow = (long long)s * P.n + wave_row0;
         // the row the action is taken from (MaskableRolloutBuffer: observations, action_masks, episode_starts)
-        if (obs_out != nullptr) wave_store_rows_f32<D, ENVS>(reinterpret_cast<float *>(lwave), o, obs_out + srow * D, n_valid, lane);
-        if (mask_out != nullptr) wave_store_rows_mask<A, ENVS>(lwave, mbits, mask_out + srow * A, n_valid, lane);
+        if (obs_out != nullptr) wave_store_rows_f32<D, ENVS>(reinterpret_cast<float *>(lwave), lrow_obs, o, obs_out + srow * D, n_valid, lane);
+        if (mask_out != nullptr) wave_store_rows_mask<A, ENVS>(lwave, lrow_mask, mbits, mask_out + srow * A, n_valid, lane);
         if (live && start_out != nullptr)
             __builtin_nontemporal_store((uint8_t)(e.step == 0 ? 1 : 0), &start_out[(long long)s * P.n + i]);
         MSE_TLB(ptl, 0); // row stores

@@ -714,8 +714,10 @@ __global__ __launch_bounds__(kRingThreads) void k_rollout_ring(Params P, uint4 *
     const int role = tid / kPoEnvs;                  // wave-uniform: 0 dynamics, 1 observer, 2 RNG
     const int el = tid - role * kPoEnvs;             // env slot inside the workgroup (same for the three roles)
     const long long row0 = (long long)blockIdx.x * kPoEnvs;
-    const long long i = row0 + el;                   // < n_pad always
-    const bool live = i < P.n;
+    // Every lane steps an env: the lanes past the batch's end (the planes are padded to whole workgroups) mirror its
+    // last env in all three roles and store nothing, so the step loops carry no per-lane "is there an env here" region.
+    const bool live = row0 + el < P.n;
+    const long long i = live ? row0 + el : P.n - 1;
 #ifdef MSE_TIMELINE
     Timeline edge;
     edge.start();
@@ -728,7 +730,7 @@ __global__ __launch_bounds__(kRingThreads) void k_rollout_ring(Params P, uint4 *
     Env e;
     EnvRaw raw;
     int sm = -1;
-    if (role == 0 && live) {
+    if (role == 0) {
         load_env_raw<KIND, NOISE>(raw, planes, P, i);
         if (KIND == 2 && sort_mode != nullptr) sm = sort_mode[i];
     }
@@ -737,7 +739,7 @@ __global__ __launch_bounds__(kRingThreads) void k_rollout_ring(Params P, uint4 *
         tc.issue(table_image, P.table_words, tid);
         tc.commit(ltab, table_image, P.table_words, tid);
     }
-    if (role == 0 && live) unpack_env<KIND, NOISE>(e, raw, P);
+    if (role == 0) unpack_env<KIND, NOISE>(e, raw, P);
     MSE_TL(edge, 0); // state loads and the table image -> LDS
 
     if (role == 2) {
@@ -759,7 +761,7 @@ __global__ __launch_bounds__(kRingThreads) void k_rollout_ring(Params P, uint4 *
         // does not cost the wave max(draws) iterations every step: the run-ahead slack (64 - 2 worst) smooths
         // the per-step spread (6 or 19 draws with the default config) towards the long-run mean.
         const uint32_t worst = (uint32_t)P.ring_worst;
-        uint32_t w = 0, need = live ? worst : 0u, cap = need; // step 0's outputs, in place before B_init
+        uint32_t w = 0, need = worst, cap = need; // step 0's outputs, in place before B_init
 #ifdef MSE_TIMELINE
         Timeline tl;
         tl.start();
@@ -782,19 +784,19 @@ __global__ __launch_bounds__(kRingThreads) void k_rollout_ring(Params P, uint4 *
             const uint32_t steps_left = (uint32_t)(k_steps - 1 - s); // steps s+1 .. K-1
             const uint32_t r = lpos[el];                             // 0 at B_init
             const uint32_t ahead = worst * steps_left;
-            need = live ? r + worst * (steps_left < 2u ? steps_left : 2u) : 0u;
-            cap = live ? r + (ahead < (uint32_t)kRingDepth ? ahead : (uint32_t)kRingDepth) : 0u;
+            need = r + worst * (steps_left < 2u ? steps_left : 2u);
+            cap = r + (ahead < (uint32_t)kRingDepth ? ahead : (uint32_t)kRingDepth);
         }
         // hand the stream back: this lane stands d <= worst outputs past what the env consumed (nothing is
         // produced after the last barrier, and before it at most `worst` per remaining step)
-        if (live) {
+        {
             uint32_t d = w - lpos[el]; // <= 64, the ring's depth
             if (__builtin_expect(d > 32u, 0)) { // only after steps that drew nothing (an episode's first two)
                 pcg_step_back(g, 32u, tb.back);
                 d -= 32u;
             }
             pcg_step_back(g, d, tb.back);
-            planes[PL_RNG_STATE * P.n_pad + i] = pack_u64x2(g.s_lo, g.s_hi);
+            if (live) planes[PL_RNG_STATE * P.n_pad + i] = pack_u64x2(g.s_lo, g.s_hi);
         }
 #ifdef MSE_TIMELINE
         tl.flush(2);
@@ -822,7 +824,7 @@ __global__ __launch_bounds__(kRingThreads) void k_rollout_ring(Params P, uint4 *
 #endif
         rng.f_min = 0xFFFFFFFFu;
         rng.f_max = 0u;
-        uint32_t cur_mask = live ? action_mask_bits<KIND>(e, P) : 1u;
+        uint32_t cur_mask = action_mask_bits<KIND>(e, P);
         const uint32_t pkey = mse_policy_key(policy_seed, (uint64_t)(P.index_offset + i));
         lpos[el] = 0;
         MSE_TL(edge, 1); // state load
@@ -832,17 +834,13 @@ __global__ __launch_bounds__(kRingThreads) void k_rollout_ring(Params P, uint4 *
         e.tl.start();
 #endif
         for (int s = 0; s < k_steps; ++s) {
-            if (live) { // padding lanes only keep the barrier count
+            {
                 const int a = policy_action<KIND>(e, cur_mask, tb, flags, pkey, policy_t0 + (uint64_t)s);
                 MSE_TL(e.tl, 0);
                 Snap sn;
                 env_dynamics<KIND, NOISE, false>(e, rng, P, tb, a, sm, flags, bales, sn);
-                if (__builtin_expect(sn.done != 0, 0)) { // all envs of a batch finish together: rare, wave-uniform
-                    int kdummy[4];
-                    auto_reset_env(e, P, tb, bales, kdummy);
-                }
-                const uint32_t mbits = action_mask_bits<KIND>(e, P); // what the next action sees (after auto-reset)
-                cur_mask = mbits;
+                // the snapshot goes to LDS before the auto-reset touches the env: the observer wants the pre-reset
+                // counters, and written first they need no second set of registers beside the env's own
                 uint32_t *w = lsnap + (s & 1) * SW * kPoEnvs + el;
 #pragma unroll
                 for (int m = 0; m < 4; ++m) {
@@ -855,11 +853,17 @@ __global__ __launch_bounds__(kRingThreads) void k_rollout_ring(Params P, uint4 *
                                   ((uint32_t)sn.st_sort << 18) | ((uint32_t)sn.mode << 20) | ((uint32_t)sn.lps << 22) |
                                   ((uint32_t)sn.done << 23) | ((uint32_t)sn.overflowed << 24);
                 w[11 * kPoEnvs] = (uint32_t)a;
-                w[12 * kPoEnvs] = mbits;
                 if (NOISE) {
 #pragma unroll
                     for (int m = 0; m < 4; ++m) w[(13 + m) * kPoEnvs] = __float_as_uint((float)sn.acc[m]);
                 }
+                if (__builtin_expect(sn.done != 0, 0)) { // all envs of a batch finish together: rare, wave-uniform
+                    int kdummy[4];
+                    auto_reset_env(e, P, tb, bales, kdummy);
+                }
+                const uint32_t mbits = action_mask_bits<KIND>(e, P); // what the next action sees (after auto-reset)
+                cur_mask = mbits;
+                w[12 * kPoEnvs] = mbits;
                 lpos[el] = rng.pos(); // r_s for the RNG lane of this env
             }
             MSE_TLB(e.tl, 5);
@@ -874,7 +878,7 @@ __global__ __launch_bounds__(kRingThreads) void k_rollout_ring(Params P, uint4 *
             // the generator state is written by the RNG lane (it steps back to the consumed position)
             store_env<KIND, NOISE>(e, planes, P, i, false, /*write_rng_state=*/false);
         }
-        if (P.track_bales) {
+        if (P.track_bales && live) {
 #pragma unroll
             for (int m = 0; m < 5; ++m) planes[(long long)(PL_BALE0 + m) * P.n_pad + i] = lbale[m * kPoEnvs + el];
         }
@@ -921,15 +925,15 @@ __global__ __launch_bounds__(kRingThreads) void k_rollout_ring(Params P, uint4 *
             sn.lps = (int)((pk >> 22) & 1u);
             sn.done = (int)((pk >> 23) & 1u);
             sn.overflowed = (int)((pk >> 24) & 1u);
-            if (live) { // the snapshot slots of padding lanes are never written
-                int k[4];
-                StepResult r = env_observe<KIND, NOISE>(sn, P, tb, k, o);
-                if (__builtin_expect(sn.done != 0, 0)) { // the step's observation is the one after the auto-reset
-                    Snap rs;
-                    snap_of_reset(rs, tb.cst);
-                    int k2[4];
-                    (void)env_observe<KIND, true>(rs, P, tb, k2, o);
-                }
+            int k[4];
+            StepResult r = env_observe<KIND, NOISE>(sn, P, tb, k, o);
+            if (__builtin_expect(sn.done != 0, 0)) { // the step's observation is the one after the auto-reset
+                Snap rs;
+                snap_of_reset(rs, tb.cst);
+                int k2[4];
+                (void)env_observe<KIND, true>(rs, P, tb, k2, o);
+            }
+            if (live) {
                 if (actions_out != nullptr) __builtin_nontemporal_store(a, &actions_out[(long long)s * P.n + i]);
                 if (reward_out != nullptr) __builtin_nontemporal_store((float)r.reward, &reward_out[(long long)s * P.n + i]);
                 if (done_out != nullptr) __builtin_nontemporal_store((uint8_t)r.done, &done_out[(long long)s * P.n + i]);

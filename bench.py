@@ -15,8 +15,9 @@ launch per step.  Inputs (state, seeds) are resident in HBM before the timed reg
 
 A pass = exactly `--steps` steps.  One pass of a short run (the driver's `--steps 20` is one 85 us launch) is
 shorter than the two device synchronisations that bracket it, so the timed region holds `reps` passes issued back
-to back (state advancing, `reps` reported; default: as many as reach ~2048 steps, `--reps 1` for a single
-pass) and value / ms_per_step are per step of that region; `single_pass_ms` is the median of individually
+to back (state advancing, `reps` reported; default: as many as reach ~65 536 steps = 0.2 s, the length from
+which the per-launch time stops falling - a region of a few ms is spent in the GPU's clock ramp; `--reps 1` for a
+single pass) and value / ms_per_step are per step of that region; `single_pass_ms` is the median of individually
 bracketed passes, sync overhead included, for comparison.
 
 Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement").
@@ -116,7 +117,7 @@ def main():
     ap.add_argument("--pipeline", type=int, default=0, choices=[0, 1, 2, 3],
                     help="mse_config.rollout_pipeline: 0 by size (default), 1 two-role, 2 one lane per env, 3 three-role ring")
     ap.add_argument("--reps", type=int, default=0,
-                    help="passes of --steps steps inside the timed region (0 = as many as reach ~2048 steps)")
+                    help="passes of --steps steps inside the timed region (0 = as many as reach ~65 536 steps)")
     ap.add_argument("--policy", default="random", choices=["random", "mlp"],
                     help="random: the on-device masked-uniform policy (headline); mlp: the reference's actor-critic MLP "
                          "evaluated inside the rollout kernel (MaskablePPO-shaped collection, BASELINE.json configs[3])")
@@ -204,7 +205,9 @@ def main():
         if world > 1:
             dist.barrier()
 
-    reps = args.reps if args.reps > 0 else max(1, -(-2048 // args.steps))
+    # default: ~65 536 steps (0.2 s) in the timed region.  Shorter regions measure the clock ramp, not the kernel: at
+    # --steps 20 a 8 ms region gives 75-77 us per launch, 70 ms 69.7, 0.27 s 68.6, 1.1 s 68.3
+    reps = args.reps if args.reps > 0 else max(1, -(-65536 // args.steps))
     run(args.warmup)
     torch.cuda.synchronize(dev)
     # individually bracketed passes first (sync on both sides of each: what a caller who waits per pass sees)

@@ -26,7 +26,7 @@ for tag, e in s["tags"].items():
 sq = s["tags"]["sq_k64"]["counters_mean_per_dispatch"]["void k_rollout_ring<3, false>"]
 print("ring: VALU issue ratio %.3f, VALU per SIMD-step %.0f" % (sq["SQ_ACTIVE_INST_VALU"] / (sq["SQ_WAVE_CYCLES"] / 3), sq["SQ_INSTS_VALU"] / 64 / 1024))
 m = [v for k, v in s["tags"]["sq_mlp_262144"]["counters_mean_per_dispatch"].items() if "policy" in k][0]
-print("policy: VALU issue ratio %.3f, VALU per wave-step %.0f, MFMA per launch %.0f" % (m["SQ_ACTIVE_INST_VALU"] / (m["SQ_WAVE_CYCLES"] / 2), m["SQ_INSTS_VALU"] / 4096 / 17, m["SQ_INSTS_MFMA"]))
+print("policy: VALU issue ratio %.3f, VALU per wave-step %.0f, MFMA per launch %.0f" % (m["SQ_ACTIVE_INST_VALU"] / (m["SQ_WAVE_CYCLES"] / 2), m["SQ_INSTS_VALU"] / 4096 / 16, m["SQ_INSTS_MFMA"]))
 for e in t["entries"]:
     print(e["policy"], e["envs"], "K", e["steps_per_launch"], "MB %.1f" % (e["hbm_bytes_per_launch"] / 1e6), "B/env-step %.1f" % (e["hbm_bytes_per_launch"] / e["envs"] / e["steps_per_launch"]))
 PY

@@ -3,7 +3,9 @@
 set -e
 SRC=gpurun_out/prof_r02; DST=profiles/r02; mkdir -p $DST
 for t in trace_k64 trace_k20 trace_k16 trace_mlp_65536 trace_mlp_262144; do
-  f=$(find $SRC/$t -name "*kernel_stats.csv" | head -1); cp "$f" $DST/${t}_kernel_stats.csv; cp $SRC/$t.json $DST/${t}_bench.json
+  # newest file: gpurun merges every run's output directory into gpurun_out/
+  f=$(find $SRC/$t -name "*kernel_stats.csv" -printf "%T@ %p\n" | sort -n | tail -1 | cut -d" " -f2)
+  cp "$f" $DST/${t}_kernel_stats.csv; cp $SRC/$t.json $DST/${t}_bench.json
 done
 cp $SRC/summary.json $DST/summary.json; cp $SRC/configs.txt $DST/configs.txt
 for f in free_driver_line free_k64 free_mlp_65536 free_mlp_262144 free_mlp_262144_k64; do cp $SRC/$f.json $DST/$f.json; done

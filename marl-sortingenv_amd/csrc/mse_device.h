@@ -1255,11 +1255,14 @@ __device__ __forceinline__ void divmod_small(int amount, int S, float inv_S, int
     }
 }
 
-// int(q * 100) of press_bale (env_super.py:664): q100 minus a bit of P.qi_down
-__device__ __forceinline__ uint32_t bale_quality_int(const Params &P, int q100)
+// int(q * 100) of press_bale (env_super.py:664): q100 minus a bit of qi_down (the 101 cases, found by the host with the
+// literal expression).  The four mask words follow the press times in the table image (ptab = Tables::press_time): a
+// lane selects one by its own q100, and a per-lane selection among kernel arguments becomes ONE global load at a
+// selected address - inside the step loop, with an s_waitcnt vmcnt(0) behind it that also waits for every output store
+// the wave has in flight (that is what the listing of round 2's kernels showed: 0.4-0.6 us per step on the critical path).
+__device__ __forceinline__ uint32_t bale_quality_int(const int *ptab, int q100)
 {
-    const uint32_t w = (uint32_t)q100 >> 5;
-    const uint32_t word = w == 0 ? P.qi_down[0] : (w == 1 ? P.qi_down[1] : (w == 2 ? P.qi_down[2] : P.qi_down[3]));
+    const uint32_t word = (uint32_t)ptab[2 + ((uint32_t)q100 >> 5)];
     return (uint32_t)q100 - ((word >> ((uint32_t)q100 & 31u)) & 1u);
 }
 
@@ -1281,10 +1284,10 @@ struct Ledger {
 //                                                          double is within 2^-52 of the true value, never across an integer)
 //   rem > S * bale_remainder_threshold                 ->  rem > P.rem_thr_units = floor(S * thr), same test on integers
 template <class BALES>
-__device__ __forceinline__ void press_bale(const BALES &bales, int m, const Params &P, int n, int q100)
+__device__ __forceinline__ void press_bale(const BALES &bales, int m, const Params &P, const int *ptab, int n, int q100)
 {
     uint4 c = bales.load(m);
-    const uint32_t qi = bale_quality_int(P, q100);
+    const uint32_t qi = bale_quality_int(ptab, q100);
     const uint32_t S = (uint32_t)P.balesize;
     int full_i, rem_i;
     if (__builtin_expect(n < (1 << 24), 1)) divmod_small(n, P.balesize, P.inv_balesize, full_i, rem_i);
@@ -1347,7 +1350,7 @@ struct BaleRefCompact {
 
 // env_super.py:626-640 press_action_rules = check_press_status (:642-659) then use_press (:722-769)
 template <bool TRACE = false, class BALES = BaleRef>
-__device__ __forceinline__ void press_action_rules(Env &e, const Params &P, int press_action, const BALES &bales,
+__device__ __forceinline__ void press_action_rules(Env &e, const Params &P, const int *ptab, int press_action, const BALES &bales,
                                                    Ledger *lg = nullptr)
 {
     // check_press_status: both timers tick; a press that reaches 0 books its bale.  A finishing press is rare per
@@ -1363,15 +1366,15 @@ __device__ __forceinline__ void press_action_rules(Env &e, const Params &P, int 
                 if (p == 0 ? fin0 : fin1) {
                     lg->bmat[lg->n_bale] = e.pmat[p];
                     lg->bn[lg->n_bale] = e.pn[p];
-                    lg->bq[lg->n_bale] = (int)bale_quality_int(P, e.q100[p]);
+                    lg->bq[lg->n_bale] = (int)bale_quality_int(ptab, e.q100[p]);
                     lg->n_bale += 1;
                 }
             }
         }
         if (P.track_bales)
-            press_bale(bales, first ? e.pmat[1] : e.pmat[0], P, first ? e.pn[1] : e.pn[0], first ? e.q100[1] : e.q100[0]);
+            press_bale(bales, first ? e.pmat[1] : e.pmat[0], P, ptab, first ? e.pn[1] : e.pn[0], first ? e.q100[1] : e.q100[0]);
         if (__builtin_expect(fin0 && fin1, 0)) { // press 0 was booked above (reference order: press 1, then 2)
-            if (P.track_bales) press_bale(bales, e.pmat[1], P, e.pn[1], e.q100[1]);
+            if (P.track_bales) press_bale(bales, e.pmat[1], P, ptab, e.pn[1], e.q100[1]);
         }
         if (fin0) {
             e.pmat[0] = 0xFF;
@@ -1457,7 +1460,7 @@ struct Tables {
     const uint32_t *pat;  // [3][kPatStride] per stage id, see kPatStride
     const double *acc;    // [3][4]       clip(baseline + boost by mode 0 | 1 | none) env_super.py:499-509
     const double *bonus;  // [4]          target_peaks[min(num_bales,3)] - bale_efficiency_factor  :1065-1069
-    const int *press_time; // [2]
+    const int *press_time; // [2] press times, then [4] the qi_down mask words (bale_quality_int)
     // rarely used fp64 constants live here too: as kernel arguments they were re-fetched with s_load inside
     // the step loop (SGPR pressure), each fetch a scalar-cache round trip
     const double *cst;     // [CST_COUNT], see enum Cst
@@ -1746,7 +1749,7 @@ __device__ __forceinline__ void env_dynamics(Env &e, RNG &rng, const Params &P, 
             }
         }
     }
-    if (run_press_rules) press_action_rules<TRACE, BALES>(e, P, press_action, bales, lg);
+    if (run_press_rules) press_action_rules<TRACE, BALES>(e, P, tb.press_time, press_action, bales, lg);
     MSE_TL(e.tl, 3);
 
     // snapshot for the observer

@@ -1733,6 +1733,7 @@ static int build_tables(const mse_config &c, Params &P, std::vector<uint32_t> &i
     P.off_ptime = (int)image.size();
     image.push_back((uint32_t)c.press_time[0]);
     image.push_back((uint32_t)c.press_time[1]);
+    for (int w = 0; w < 4; ++w) image.push_back(P.qi_down[w]); // bale_quality_int's mask (set by mse_create before this)
     P.off_cst = (int)image.size(); // even: every section so far has an even word count after off_tanh
     {
         double cst[CST_COUNT] = {};

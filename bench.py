@@ -36,8 +36,8 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 # SQ_ACTIVE_INST_VALU / (SQ_WAVE_CYCLES / waves per SIMD), profiles/r02/summary.json (tags sq_k64, sq_mlp_262144): the
-# share of cycles in which a SIMD's VALU is issuing - k_rollout_ring 0.83 (3 waves per SIMD), k_rollout_policy 0.87 (2)
-VALU_ISSUE_RATIO = {"random": 0.83, "mlp": 0.87}
+# share of cycles in which a SIMD's VALU is issuing - k_rollout_ring 0.85 (3 waves per SIMD), k_rollout_policy 0.88 (2)
+VALU_ISSUE_RATIO = {"random": 0.85, "mlp": 0.88}
 F16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense f16 / bf16 matrix peak
 
 

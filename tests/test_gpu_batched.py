@@ -415,3 +415,25 @@ def test_general_generator_rollout_equals_step(kind, policy):
         assert torch.equal(done, buf["done"][k]) and torch.equal(mask, buf["mask"][k])
     for x, y in zip(a.get_state(), b.get_state()):
         assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize("n", [1, 2, 257])
+@pytest.mark.parametrize("kind", KINDS)
+def test_tiny_batches_through_the_three_role_kernel(kind, n):
+    """Batches far below a workgroup: every lane past the batch's end mirrors the last env (all three wave roles) and
+    stores nothing - buffers and final state equal the one-lane kernel's, and equal the first n envs of a larger batch
+    (an env's results do not depend on who sits beside it)."""
+    import torch
+
+    kw = dict(base_seed=5, max_steps=12, noise_sorting=0.05, balesize=200, auto_reset=True)
+    a = _mk(kind, n, rollout_pipeline=3, **kw)
+    b = _mk(kind, n, rollout_pipeline=2, **kw)
+    big = _mk(kind, 300, rollout_pipeline=3, **kw)
+    for chunk in (30, 1, 7):
+        ra, rb, rc = a.rollout(chunk, policy_seed=8), b.rollout(chunk, policy_seed=8), big.rollout(chunk, policy_seed=8)
+        for key in ra:
+            assert torch.equal(ra[key], rb[key]), (key, chunk)
+            assert torch.equal(ra[key], rc[key][:, :n]), (key, chunk)
+        for x, y in zip(a.get_state(), b.get_state()):
+            assert torch.equal(x, y), chunk
+    assert a.error_count() == 0

@@ -240,6 +240,9 @@ int mse_model_actions(mse_env *env, uint32_t flags, int32_t *action_out, void *s
 #define MSE_TRACE_INTERNAL   31 /* Env_1: the press action sampled inside the env (env_1_sort.py:125)             */
 #define MSE_TRACE_REWARD     32 /* the step's reward (f64)                                                        */
 #define MSE_TRACE_ACC_BELT   33 /* [4] accuracy_belt after the step (the next step's accuracy_sorter)             */
+#define MSE_TRACE_OVERFLOW   37 /* check_overflow terminated the episode: 1 + index of the first material A..E whose
+                                   level exceeds the capacity (detect_overflow, env_super.py:900-905: the reference's
+                                   info["overflow_material"]), else 0                                                */
 int mse_trace_begin(mse_env *env, int64_t env_index, double *records_dev, int64_t capacity);
 int mse_trace_end(mse_env *env, int64_t *n_records_out);
 

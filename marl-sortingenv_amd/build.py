@@ -8,7 +8,8 @@ import subprocess
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 REPO_ROOT = os.path.dirname(PKG_DIR)
 SOURCES = [os.path.join(PKG_DIR, "csrc", "mse_lib.hip"), os.path.join(PKG_DIR, "csrc", "mse_policy.hip")]
-HEADERS = [os.path.join(PKG_DIR, "csrc", "mse_device.h"), os.path.join(REPO_ROOT, "include", "mse.h")]
+HEADERS = [os.path.join(PKG_DIR, "csrc", h) for h in ("mse_device.h", "mse_policy_device.h", "mse_policy_stream.h")] + \
+          [os.path.join(REPO_ROOT, "include", "mse.h")]
 LIB_PATH = os.environ.get("MSE_LIB_PATH") or os.path.join(PKG_DIR, "libmse_hip.so")  # override: experiments only
 
 HIPCC_FLAGS = [

@@ -378,6 +378,14 @@ __global__ __launch_bounds__(kBlock) void k_step(Params P, uint4 *__restrict__ p
             t[MSE_TRACE_INTERNAL] = (double)lg.internal;
             t[MSE_TRACE_REWARD] = r.reward;
             for (int m = 0; m < 4; ++m) t[MSE_TRACE_ACC_BELT + m] = e.acc[m];
+            int ovf = 0; // env_super.py:900-905 detect_overflow: the first material above capacity
+            if ((flags & MSE_STEP_CHECK_OVERFLOW) && r.done) {
+                for (int m = 4; m >= 0; --m) {
+                    const int lvl = m < 4 ? e.ct[m] + e.cf[m] : e.ce;
+                    if (lvl > P.capacity) ovf = m + 1;
+                }
+            }
+            t[MSE_TRACE_OVERFLOW] = (double)ovf;
         }
         if (r.done && P.auto_reset) {
             if (terminal_obs_out != nullptr) {
@@ -814,7 +822,7 @@ __global__ __launch_bounds__(kRingThreads) void k_rollout_ring(Params P, uint4 *
         __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): no load is outstanding inside the step loop
         RngRing rng;
         rng.lane_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)(lring + el);
-        if ((rng.lane_addr & 0xFC00u) != 0u) __builtin_trap(); // the ring must start on a 64 KiB LDS boundary
+        // (the ring starts at LDS address 0: RingLayout::ring_offset == 0 and ring_kernels_static_lds_free(), checked at mse_create)
         rng.jump_tab = tb.jump;
         rng.start = e.rng;
         rng.p10 = 0;
@@ -1849,6 +1857,26 @@ static void launch_step(mse_env *h, hipStream_t s, const int32_t *action, const 
 #undef MSE_LAUNCH_STEP
 }
 
+// RngRing::load masks an output's row into the lane's LDS address, which needs the ring on a 64 KiB LDS boundary:
+// ring_offset == 0 inside the dynamic LDS block, and the dynamic block itself at LDS address 0, i.e. no static
+// __shared__ in these kernels.  A property of the build; checked once on the host (mse_create) instead of by a trap
+// in the kernel.
+static bool ring_kernels_static_lds_free()
+{
+    static int cached = -1;
+    if (cached < 0) {
+        const void *fns[] = {(const void *)k_rollout_ring<1, false>, (const void *)k_rollout_ring<1, true>,
+                             (const void *)k_rollout_ring<2, false>, (const void *)k_rollout_ring<2, true>,
+                             (const void *)k_rollout_ring<3, false>, (const void *)k_rollout_ring<3, true>};
+        cached = 1;
+        for (const void *f : fns) {
+            hipFuncAttributes a{};
+            if (hipFuncGetAttributes(&a, f) != hipSuccess || a.sharedSizeBytes != 0) cached = 0;
+        }
+    }
+    return cached == 1;
+}
+
 template <int KIND>
 static void launch_rollout(mse_env *h, hipStream_t s, int k_steps, uint64_t policy_seed, const int32_t *sort_mode,
                            uint32_t flags, int32_t *actions, float *obs, float *rew, uint8_t *done, uint8_t *mask)
@@ -2149,7 +2177,7 @@ int mse_create_indexed(mse_env **out, const mse_config *cfg, int64_t n_envs, int
         else if (cfg->env_kind == MSE_ENV_PRESS) ring_lds += nz ? RingLayout<2, true>::table_offset : RingLayout<2, false>::table_offset;
         else ring_lds += nz ? RingLayout<3, true>::table_offset : RingLayout<3, false>::table_offset;
         P.ring_worst = worst;
-        const bool fits = worst <= kRingMaxPerStep && !h->literal && ring_lds <= (size_t)160 * 1024;
+        const bool fits = worst <= kRingMaxPerStep && !h->literal && ring_lds <= (size_t)160 * 1024 && ring_kernels_static_lds_free();
         h->ring = h->pipelined && fits && cfg->rollout_pipeline != 1;
         if (cfg->rollout_pipeline == 3 && !fits) {
             delete h; // nothing is allocated on the device yet
@@ -2411,6 +2439,7 @@ int mse_action_masks(mse_env *h, uint8_t *mask_out, void *stream)
 int mse_sort_agent_obs(mse_env *h, float *obs13_out, void *stream)
 {
     if (!h || !obs13_out) return fail(MSE_ERR_INVALID_ARGUMENT, "env/obs13_out is NULL");
+    if (!h->seeded) return fail(MSE_ERR_NOT_RESET, "mse_sort_agent_obs before the first seeded mse_reset");
     hipLaunchKernelGGL(k_sort_agent_obs, grid_of(h), dim3(kBlock), 0, static_cast<hipStream_t>(stream), h->P, h->planes,
                        h->tables, obs13_out);
     MSE_CHECK_LAUNCH();
@@ -2420,6 +2449,7 @@ int mse_sort_agent_obs(mse_env *h, float *obs13_out, void *stream)
 int mse_press_agent_obs(mse_env *h, float *obs16_out, void *stream)
 {
     if (!h || !obs16_out) return fail(MSE_ERR_INVALID_ARGUMENT, "env/obs16_out is NULL");
+    if (!h->seeded) return fail(MSE_ERR_NOT_RESET, "mse_press_agent_obs before the first seeded mse_reset");
     hipLaunchKernelGGL(k_press_agent_obs, grid_of(h), dim3(kBlock), 0, static_cast<hipStream_t>(stream), h->P, h->planes,
                        h->tables, obs16_out);
     MSE_CHECK_LAUNCH();

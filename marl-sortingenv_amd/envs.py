@@ -21,7 +21,7 @@ import torch
 
 from .batched import BatchedSortingEnv
 from .config import NUM_ACTIONS, OBS_DIM, SortingEnvConfig
-from .trace import ACC_BELT, MATERIALS, EnvTrace
+from .trace import ACC_BELT, INTERNAL, MATERIALS, OVERFLOW, EnvTrace
 
 try:  # pragma: no cover - not installed in the build container
     import gymnasium as _gym
@@ -114,6 +114,7 @@ class _SingleEnv(_EnvBase):
         self._action = torch.zeros(1, dtype=torch.int32, device=self._batched.device)
         self._sort_mode = torch.zeros(1, dtype=torch.int32, device=self._batched.device)
         self.current_step = 0
+        self._overflow = None
         self._trace = EnvTrace(balesize if balesize is not None else cfg.bale_standard_size, cfg.bale_remainder_threshold)
         self._batched.trace_begin(0, _TRACE_CAPACITY)
 
@@ -168,7 +169,21 @@ class _SingleEnv(_EnvBase):
         self.current_step += 1
         reward = float(self._batched.reward64[0].item())
         terminated = bool(done[0].item())
+        self._overflow = None
+        if check_overflow and terminated:
+            # env_monolith.py:264-268, env_1_sort.py:131-139, env_2_press.py:144-150: an overflow termination reports
+            # the material detect_overflow() found (env_super.py:900-905); the engine's trace record carries it
+            rec = self._batched.trace_records()[-1].cpu().numpy()
+            if int(rec[OVERFLOW]) > 0:
+                self._overflow = (MATERIALS[int(rec[OVERFLOW]) - 1], int(rec[INTERNAL]))
         return obs[0].cpu().numpy(), reward, terminated, False
+
+    def _info(self, action):
+        """The step's info dict: {"action": a}, with the reference's overflow keys in front when check_overflow
+        ended the episode."""
+        if self._overflow is not None:
+            return {"overflow": True, "overflow_material": self._overflow[0], "action": action}
+        return {"action": action}
 
     # -- copy.deepcopy(env.unwrapped) (src/training.py:82): an independent env in the same state --------------------
     def __deepcopy__(self, memo):
@@ -297,6 +312,11 @@ class Env_1_Sorting(_SingleEnv):
 
     def step(self, action=None, use_action_masking=True, check_overflow=False):
         obs, reward, terminated, truncated = self._step(action, None, use_action_masking, check_overflow)
+        if self._overflow is not None:
+            # env_1_sort.py:125,139: on overflow "action" is the press job the env sampled itself, in
+            # press_discrete_to_action's form [press_id, material_id] / [0, None] (env_super.py:804-809)
+            a = self._overflow[1]
+            return obs, reward, terminated, truncated, self._info([0, None] if a == 0 else [1 if a <= 5 else 2, (a - 1) % 5])
         return obs, reward, terminated, truncated, {"action": action}
 
 
@@ -322,7 +342,7 @@ class Env_2_Pressing(_SingleEnv):
             sort_mode, _ = self.sort_agent.predict(sort_obs, deterministic=True)
             sort_mode = int(sort_mode)
         obs, reward, terminated, truncated = self._step(action, sort_mode, use_action_masking, check_overflow)
-        return obs, reward, terminated, truncated, {"action": int(action)}
+        return obs, reward, terminated, truncated, self._info(int(action))
 
 
 class Env_3_Monolith(_SingleEnv):
@@ -344,7 +364,11 @@ class Env_3_Monolith(_SingleEnv):
         if action is not None:
             action = int(action)
         elif self.mono_agent is not None:                                   # env_monolith.py:144-150
-            action, _ = self.mono_agent.predict(self.get_obs(), deterministic=True, action_masks=self.action_masks())
+            # the agent sees get_obs() AFTER this step's flow update (:113-114, 145 -> :98-104): the two previews of
+            # the coming step, concatenated; the mask does not depend on the flow update
+            obs = np.concatenate([self._batched.sort_agent_obs()[0].cpu().numpy(),
+                                  self._batched.press_agent_obs()[0].cpu().numpy()])
+            action, _ = self.mono_agent.predict(obs, deterministic=True, action_masks=self.action_masks())
             action, masked = int(action), True                              # applied without sanitising (:254-257)
         elif mode == "random":                                              # env_monolith.py:152-164
             # the reference draws from the process-global np.random, which reset(seed) seeds (env_super.py:177)
@@ -362,7 +386,7 @@ class Env_3_Monolith(_SingleEnv):
             raise ValueError("Invalid action source: Provide 'action', set 'mode' to 'random', 'rule_based', or "
                              "'model', or assign a mono_agent.")
         obs, reward, terminated, truncated = self._step(action, None, masked, check_overflow, sanitize_late=late)
-        return obs, reward, terminated, truncated, {"action": action}
+        return obs, reward, terminated, truncated, self._info(action)
 
     def _model_action(self, use_action_masking):
         """Modular agents, each falling back to the env's own random draw when absent (env_monolith.py:186-221)."""

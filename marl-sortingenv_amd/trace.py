@@ -15,6 +15,7 @@ MATERIALS = ["A", "B", "C", "D", "E"]
 # column map of one record (include/mse.h)
 ACTION, R_SORT, R_PRESS, SETTING, BELT, CONT_TRUE, CONT_FALSE, CONT_E = 0, 1, 2, 3, 4, 8, 12, 16
 N_LOG, LOG, N_BALE, BALE, DONE, STEP, INTERNAL, REWARD, ACC_BELT = 17, 18, 22, 23, 29, 30, 31, 32, 33
+OVERFLOW = 37  # 1 + index of the material that overflowed when check_overflow ended the episode, else 0
 
 
 class EnvTrace:

@@ -242,7 +242,8 @@ def main():
     print(f"total {total/1024:.1f} KiB")
 
 
-if __name__ == "__main__" and not any(a in sys.argv for a in ("--rule-based", "--model", "--trace", "--random-mode")):
+if __name__ == "__main__" and not any(a in sys.argv for a in ("--rule-based", "--model", "--trace", "--random-mode", "--agents",
+                                                              "--overflow-info")):
     main()
 
 
@@ -408,3 +409,182 @@ if __name__ == "__main__" and "--model" in sys.argv:
     gen_model_fallback()
 if __name__ == "__main__" and "--trace" in sys.argv:
     gen_trace()
+
+
+def gen_agents():
+    """Env_3_Monolith.step(action=None, ...) with AGENTS assigned, scripted and recording (oracle/ref_harness.py):
+      agents_mono_monoagent_*  a stored mono_agent (env_monolith.py:144-150): `agent_obs` f32[rows, 29] and `agent_mask`
+                               u8[rows, 22] are what the reference handed predict() inside each step - get_obs() AFTER
+                               the step's flow update - `arg` the action it answered (info["action"]);
+      agents_mono_model_*      mode='model' (env_monolith.py:186-221) with a sort_agent and / or a press_agent, maskable
+                               or not: `sort_agent_obs` f32[rows, 13], `press_agent_obs` f32[rows, 16], `press_agent_mask`
+                               u8[rows, 11] with `press_agent_has_mask` u8[rows]; a part no agent decides is the env's own
+                               rng_sorting / rng_pressing draw.
+    Same row format as the step traces otherwise; the agents' answers are a function of a fixture PRNG and the mask."""
+    cls = ref_harness.load()["mono"]
+    cases = (
+        # name, noise, seeds, segment, masking, mono | (sort agent?, press agent: None | "maskable" | "plain"), respect mask?
+        ("agents_mono_monoagent_n0_s3_s21", 0.0, [3, 21], 210, True, "mono", True),
+        ("agents_mono_monoagent_n5_ignoremask_s4_s9", 0.05, [4, 9], 210, True, "mono", False),
+        ("agents_mono_model_both_maskable_n0_s6_s15", 0.0, [6, 15], 210, True, (True, "maskable"), True),
+        ("agents_mono_model_both_plain_n5_s8_s2", 0.05, [8, 2], 210, True, (True, "plain"), False),
+        ("agents_mono_model_sortonly_n0_s10_s33", 0.0, [10, 33], 210, True, (True, None), True),
+        ("agents_mono_model_pressonly_n5_unmasked_s12_s5", 0.05, [12, 5], 210, False, (False, "maskable"), False),
+    )
+    for name, noise, seeds, seg, masking, who, respect in cases:
+        env = cls(max_steps=200, seed=seeds[0], noise_sorting=noise, balesize=200)
+        prng = np.random.default_rng(sum(name.encode()) * 15485863)
+        n_act = 22 if who == "mono" else 11
+
+        def decide(mask, prng=prng, n_act=n_act, respect=respect):
+            if mask is not None and respect:
+                return prng.choice(np.flatnonzero(mask))
+            return prng.integers(0, n_act)       # an agent that ignores (or never sees) the mask
+
+        sort_agent = press_agent = mono_agent = None
+        if who == "mono":
+            mono_agent = ref_harness.ScriptedMonoAgent(decide)
+            env.set_agents(mono_agent=mono_agent)
+        else:
+            if who[0]:
+                sort_agent = ref_harness.ScriptedSortAgent()
+            if who[1] is not None:
+                press_agent = (ref_harness.MaskableScriptedPressAgent if who[1] == "maskable" else ref_harness.ScriptedPressAgent)(decide)
+            env.set_agents(sort_agent=sort_agent, press_agent=press_agent)
+        rows = {k: [] for k in ("op", "arg", "sort_mode", "flags", "obs", "reward", "terminated", "mask", "ints", "dbls", "rng")}
+        extra = {k: [] for k in ("agent_obs", "agent_mask", "sort_agent_obs", "press_agent_obs", "press_agent_mask", "press_agent_has_mask")}
+
+        def record(op, arg, obs, rew, term):
+            I, Dd, R = ref_harness.snapshot(env)
+            for k, v in (("op", op), ("arg", arg), ("sort_mode", -1), ("flags", 0), ("obs", np.asarray(obs, dtype=np.float32)),
+                         ("reward", float(rew)), ("terminated", int(term)), ("mask", np.asarray(env.action_masks(), dtype=np.uint8)),
+                         ("ints", I), ("dbls", Dd), ("rng", R)):
+                rows[k].append(v)
+
+        def record_agents(step):
+            z13, z16, z11 = np.zeros(13, np.float32), np.zeros(16, np.float32), np.zeros(11, np.uint8)
+            extra["agent_obs"].append(mono_agent.last_obs if step and mono_agent else np.zeros(29, np.float32))
+            extra["agent_mask"].append(mono_agent.last_mask if step and mono_agent else np.zeros(22, np.uint8))
+            extra["sort_agent_obs"].append(sort_agent.last_obs if step and sort_agent else z13)
+            extra["press_agent_obs"].append(press_agent.last_obs if step and press_agent else z16)
+            has = bool(step and press_agent and press_agent.last_mask is not None)
+            extra["press_agent_mask"].append(press_agent.last_mask if has else z11)
+            extra["press_agent_has_mask"].append(int(has))
+
+        for seed in seeds:
+            obs, _ = env.reset(seed=seed)
+            record(1, seed, obs, 0.0, 0)
+            record_agents(False)
+            for _ in range(seg):
+                if sort_agent is not None:
+                    sort_agent.next_mode = int(prng.integers(0, 2))
+                if who == "mono":
+                    obs, rew, term, trunc, info = env.step()                     # every argument at its default
+                else:
+                    obs, rew, term, trunc, info = env.step(action=None, mode="model", use_action_masking=masking)
+                record(0, int(info["action"]), obs, rew, term)
+                record_agents(True)
+        meta = dict(name=name, kind="mono", max_steps=200, noise_sorting=noise, balesize=200, ctor_seed=int(seeds[0]),
+                    policy="stored mono_agent" if who == "mono" else "mode='model' with agents", masking=bool(masking),
+                    agents=dict(mono=who == "mono", sort=bool(who != "mono" and who[0]),
+                                press=(None if who == "mono" else who[1])),
+                    check_overflow=False, numpy=np.__version__, config_overrides={},
+                    generator="oracle/gen_golden.py --agents from the imported reference")
+        out = _pack(rows, meta)
+        out["agent_obs"] = np.asarray(extra["agent_obs"], dtype=np.float32)
+        out["agent_mask"] = np.asarray(extra["agent_mask"], dtype=np.uint8)
+        out["sort_agent_obs"] = np.asarray(extra["sort_agent_obs"], dtype=np.float32)
+        out["press_agent_obs"] = np.asarray(extra["press_agent_obs"], dtype=np.float32)
+        out["press_agent_mask"] = np.asarray(extra["press_agent_mask"], dtype=np.uint8)
+        out["press_agent_has_mask"] = np.asarray(extra["press_agent_has_mask"], dtype=np.uint8)
+        path = os.path.join(OUT_DIR, name + ".npz")
+        np.savez_compressed(path, **out)
+        print(f"{name:52s} rows={len(out['op']):4d}  {os.path.getsize(path)/1024:7.1f} KiB")
+
+
+CONFIG_D = {"pressing_station": {"press_times": {1: 1, 2: 1}, "container_capacity": 260}}
+
+
+def gen_overflow_info():
+    """step(..., check_overflow=True) until the overflow termination, several episodes per fixture, with the `info`
+    dict the reference returned (env_monolith.py:264-268, env_2_press.py:144-150, env_1_sort.py:131-139):
+    `info_overflow` u8, `info_material` i8 (0..4 = A..E, -1 = key absent), `info_action` i16 (the "action" value;
+    Env_1's overflow case reports the press job [press_id, material_id] it sampled itself, stored as its discrete
+    code (press_id - 1) * 5 + material_id + 1, [0, None] as 0).  Under CONFIG_D (1-step presses, capacity 260) a policy
+    that presses the fullest container but never material X makes X the one that overflows, E included."""
+    classes = ref_harness.load()
+    cases = (
+        ("info_mono_n5_noop_s1_s2_s7", "mono", dict(max_steps=200, noise_sorting=0.05, balesize=200), [1, 2, 7], "noop", None, None),
+        ("info_mono_cfgD_n0_avoidE_s3_s4", "mono", dict(max_steps=200, noise_sorting=0.0, balesize=20), [3, 4], "avoid", 4, CONFIG_D),
+        ("info_mono_cfgD_n5_avoidC_s5_s6", "mono", dict(max_steps=200, noise_sorting=0.05, balesize=20), [5, 6], "avoid", 2, CONFIG_D),
+        ("info_press_cfgD_n0_avoidE_s8_s9", "press", dict(max_steps=200, noise_sorting=0.0, balesize=20), [8, 9], "avoid", 4, CONFIG_D),
+        ("info_press_cfgD_n5_avoidD_s10_s11", "press", dict(max_steps=200, noise_sorting=0.05, balesize=20), [10, 11], "avoid", 3, CONFIG_D),
+        ("info_press_n0_maxsteps_s12", "press", dict(max_steps=5, noise_sorting=0.0, balesize=200), [12, 13], "noop", None, None),
+        ("info_sort_n5_s14_s15_s16", "sort", dict(max_steps=200, noise_sorting=0.05, balesize=200), [14, 15, 16], "noop", None, None),
+        ("info_sort_cfgD_n0_s17_s18", "sort", dict(max_steps=200, noise_sorting=0.0, balesize=250), [17, 18], "noop", None, CONFIG_D),
+    )
+    for name, kind, kw, seeds, policy, avoid, overrides in cases:
+        env = _construct(classes[kind], seeds[0], kw, overrides)
+        agent = None
+        if kind == "press":
+            agent = ref_harness.ScriptedSortAgent()
+            env.set_agents(sort_agent=agent)
+        prng = np.random.default_rng(sum(name.encode()) * 32452843)
+        rows = {k: [] for k in ("op", "arg", "sort_mode", "flags", "obs", "reward", "terminated", "mask", "ints", "dbls", "rng")}
+        info_rows = []
+
+        def record(op, arg, sm, flags, obs, rew, term, info):
+            I, Dd, R = ref_harness.snapshot(env)
+            for k, v in (("op", op), ("arg", arg), ("sort_mode", sm), ("flags", flags), ("obs", np.asarray(obs, dtype=np.float32)),
+                         ("reward", float(rew)), ("terminated", int(term)), ("mask", np.asarray(env.action_masks(), dtype=np.uint8)),
+                         ("ints", I), ("dbls", Dd), ("rng", R)):
+                rows[k].append(v)
+            a = info.get("action", 0)
+            if isinstance(a, (list, tuple)):                       # Env_1's overflow case: the sampled press job
+                a = 0 if not a[0] else (int(a[0]) - 1) * 5 + int(a[1]) + 1
+            assert set(info) <= {"overflow", "overflow_material", "action"}
+            info_rows.append((int(bool(info.get("overflow", False))),
+                              ref_harness.MATERIALS.index(info["overflow_material"]) if "overflow_material" in info else -1, int(a)))
+
+        for seed in seeds:
+            obs, _ = env.reset(seed=seed)
+            record(1, seed, -1, 0, obs, 0.0, 0, {})
+            for t in range(kw["max_steps"]):
+                sm = int(prng.integers(0, 2))
+                if policy == "noop":
+                    a = sm if kind == "sort" else (11 * sm if kind == "mono" else 0)
+                else:  # press the fullest container except `avoid`, if the mask allows it
+                    mask = np.asarray(env.action_masks(), dtype=bool)[:11]
+                    cm = env.container_materials
+                    lvl = [cm[m] + cm.get(m + "_False", 0) for m in "ABCDE"]
+                    order = [m for m in np.argsort(lvl)[::-1] if m != avoid]
+                    p = 0
+                    for m in order:
+                        cand = [c for c in (1 + m, 6 + m) if mask[c]]
+                        if cand:
+                            p = cand[0]
+                            break
+                    a = p + 11 * sm if kind == "mono" else p
+                if kind == "press":
+                    agent.next_mode = sm
+                obs, rew, term, trunc, info = env.step(a, use_action_masking=True, check_overflow=True)
+                record(0, a, sm if kind == "press" else -1, STEP_CHECK_OVERFLOW, obs, rew, term, info)
+                if term:
+                    break
+        meta = dict(name=name, kind=kind, max_steps=kw["max_steps"], noise_sorting=kw["noise_sorting"], balesize=kw["balesize"],
+                    ctor_seed=int(seeds[0]), policy=policy if avoid is None else f"fullest container except {'ABCDE'[avoid]}",
+                    masking=True, check_overflow=True, numpy=np.__version__, config_overrides=overrides or {},
+                    generator="oracle/gen_golden.py --overflow-info from the imported reference")
+        out = _pack(rows, meta)
+        inf = np.asarray(info_rows, dtype=np.int64)
+        out["info_overflow"], out["info_material"], out["info_action"] = inf[:, 0].astype(np.uint8), inf[:, 1].astype(np.int8), inf[:, 2].astype(np.int16)
+        path = os.path.join(OUT_DIR, name + ".npz")
+        np.savez_compressed(path, **out)
+        ends = [(int(m), int(t)) for m, t, o in zip(out["info_material"], out["terminated"], out["op"]) if t]
+        print(f"{name:44s} rows={len(out['op']):4d} episode ends (material, terminated)={ends}  {os.path.getsize(path)/1024:6.1f} KiB")
+
+
+if __name__ == "__main__" and "--agents" in sys.argv:
+    gen_agents()
+if __name__ == "__main__" and "--overflow-info" in sys.argv:
+    gen_overflow_info()

@@ -582,6 +582,16 @@ void orc_env_sort_agent_obs(const orc_env *e, float *o)
     sort_obs(&tmp, o);
 }
 
+/* What Env_3_Monolith.step hands a press_agent in mode='model' (env_monolith.py:198-210) and, concatenated behind
+ * the sorting view, a stored mono_agent (env_monolith.py:113-114,144-146 -> :98-104): get_press_obs() after this
+ * step's flow update.  The same preview as above: the env is not changed. */
+void orc_env_press_agent_obs(const orc_env *e, float *o)
+{
+    orc_env tmp = *e; /* shallow copy: press_obs reads no bale list */
+    update_environment(&tmp);
+    press_obs(&tmp, o);
+}
+
 /* env_super.py:484-509 set_multisensor_mode + update_accuracy */
 static void update_accuracy(orc_env *e, int mode)
 {
@@ -813,7 +823,7 @@ static double press_reward(orc_env *e)
 static int detect_overflow(const orc_env *e)
 {
     for (int m = 0; m < 5; ++m)
-        if (level_of(e, m) > e->cfg.container_capacity) return 1;
+        if (level_of(e, m) > e->cfg.container_capacity) return m + 1; /* (True, material m) */
     return 0;
 }
 
@@ -882,7 +892,8 @@ int orc_env_step(orc_env *e, int32_t action, int32_t sort_mode_in, uint32_t flag
      * no-op entry after it, so the last entry reads as a no-op there. */
     if (run_press_rules) press_action_rules(e, press_action);
 
-    if ((flags & ORC_STEP_CHECK_OVERFLOW) && detect_overflow(e)) {
+    e->step_overflow = (flags & ORC_STEP_CHECK_OVERFLOW) ? detect_overflow(e) : 0;
+    if (e->step_overflow) {
         /* env_monolith.py:265-272 and the variants' equivalents */
         e->current_step += 1;
         if (obs_out) orc_env_obs(e, obs_out);
@@ -982,13 +993,16 @@ void orc_env_snapshot(const orc_env *e, int64_t *I, double *D, uint64_t *R)
  *  mode='model' without agents, trace record, bale lists
  * ====================================================================================== */
 
-/* env_monolith.py:186-221 with sort_agent = press_agent = None */
-int32_t orc_env_model_fallback_action(orc_env *e, int use_action_masking)
+/* env_monolith.py:186-221: each part of the action is the env's own draw unless an agent decides it (draw_* = 0:
+ * no draw from that stream, the part comes back as 0) */
+int32_t orc_env_model_action(orc_env *e, int use_action_masking, int draw_sort, int draw_press)
 {
     /* :195 rng_sorting.choice([0, 1]): an index draw over two entries */
-    int sort_mode = (int)orc_pcg64_integers(&e->rng_sorting, 0, 2);
+    int sort_mode = draw_sort ? (int)orc_pcg64_integers(&e->rng_sorting, 0, 2) : 0;
     int press_action;
-    if (use_action_masking) { /* :213-217 rng_pressing.choice(flatnonzero(press_action_masks())) */
+    if (!draw_press) {
+        press_action = 0;
+    } else if (use_action_masking) { /* :213-217 rng_pressing.choice(flatnonzero(press_action_masks())) */
         uint8_t m11[11];
         int valid[11], n = 0;
         press_mask(e, m11);
@@ -999,6 +1013,12 @@ int32_t orc_env_model_fallback_action(orc_env *e, int use_action_masking)
         press_action = (int)orc_pcg64_integers(&e->rng_pressing, 0, 11);
     }
     return sort_mode * 11 + press_action; /* :221 */
+}
+
+/* the same with sort_agent = press_agent = None */
+int32_t orc_env_model_fallback_action(orc_env *e, int use_action_masking)
+{
+    return orc_env_model_action(e, use_action_masking, 1, 1);
 }
 
 void orc_env_trace_record(const orc_env *e, double *t)
@@ -1028,6 +1048,7 @@ void orc_env_trace_record(const orc_env *e, double *t)
     t[31] = e->last_internal_press_action;
     t[32] = e->step_reward;
     for (int m = 0; m < 4; ++m) t[33 + m] = e->acc_belt[m];
+    t[37] = e->step_overflow; /* info["overflow_material"] + 1 (env_monolith.py:264-268) */
 }
 
 int32_t orc_env_bales(const orc_env *e, int m, int64_t *sizes, int32_t *qs, int32_t cap)

@@ -126,7 +126,7 @@ typedef struct {
     int32_t step_n_bale, step_bale_mat[2], step_bale_q[2];
     int64_t step_bale_n[2];
     double  step_r_sort, step_r_press, step_reward;
-    int32_t step_action, step_done;
+    int32_t step_action, step_done, step_overflow;
 } orc_env;
 
 void orc_config_default(orc_config *cfg);
@@ -145,6 +145,7 @@ int orc_env_step(orc_env *e, int32_t action, int32_t sort_mode, uint32_t flags,
 void orc_env_action_mask(const orc_env *e, uint8_t *mask_out);
 void orc_env_obs(const orc_env *e, float *obs_out);
 void orc_env_sort_agent_obs(const orc_env *e, float *obs13_out); /* env_2_press.py:101: the sorting agent's view */
+void orc_env_press_agent_obs(const orc_env *e, float *obs16_out); /* env_monolith.py:198: the press agent's view */
 int  orc_env_obs_dim(const orc_env *e);
 int  orc_env_num_actions(const orc_env *e);
 
@@ -159,6 +160,7 @@ void orc_env_snapshot(const orc_env *e, int64_t *ints, double *dbls, uint64_t *r
  * rng_pressing.choice(11) (unmasked); returns mode * 11 + press action.  The caller steps it with masked
  * semantics (env_monolith.py:254-257 applies it through press_action_rules without sanitising). */
 int32_t orc_env_model_fallback_action(orc_env *e, int use_action_masking);
+int32_t orc_env_model_action(orc_env *e, int use_action_masking, int draw_sort, int draw_press);
 
 /* the last step as one trace record, column layout of include/mse.h MSE_TRACE_* (40 doubles) */
 void orc_env_trace_record(const orc_env *e, double *rec40);

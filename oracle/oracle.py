@@ -109,6 +109,7 @@ def lib() -> C.CDLL:
         L.orc_env_action_mask.argtypes = [C.c_void_p, P(C.c_uint8)]
         L.orc_env_obs.argtypes = [C.c_void_p, P(C.c_float)]
         L.orc_env_sort_agent_obs.argtypes = [C.c_void_p, P(C.c_float)]
+        L.orc_env_press_agent_obs.argtypes = [C.c_void_p, P(C.c_float)]
         L.orc_env_obs_dim.argtypes = [C.c_void_p]
         L.orc_env_obs_dim.restype = C.c_int
         L.orc_env_num_actions.argtypes = [C.c_void_p]
@@ -116,6 +117,8 @@ def lib() -> C.CDLL:
         L.orc_env_snapshot.argtypes = [C.c_void_p, P(i64), P(dbl), P(u64)]
         L.orc_env_model_fallback_action.argtypes = [C.c_void_p, C.c_int]
         L.orc_env_model_fallback_action.restype = i32
+        L.orc_env_model_action.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+        L.orc_env_model_action.restype = i32
         L.orc_env_trace_record.argtypes = [C.c_void_p, P(dbl)]
         L.orc_env_bales.argtypes = [C.c_void_p, C.c_int, P(i64), P(i32), i32]
         L.orc_env_bales.restype = i32
@@ -195,6 +198,13 @@ class OracleEnv:
         self.L.orc_env_sort_agent_obs(self._h, o.ctypes.data_as(C.POINTER(C.c_float)))
         return o
 
+    def press_agent_obs(self):
+        """get_press_obs() after the coming step's flow update: what Env_3_Monolith.step(mode='model') hands its
+        press_agent (env_monolith.py:198) and - behind sort_agent_obs() - a stored mono_agent (:144-146)."""
+        o = np.zeros(16, dtype=np.float32)
+        self.L.orc_env_press_agent_obs(self._h, o.ctypes.data_as(C.POINTER(C.c_float)))
+        return o
+
     def snapshot(self):
         ints = np.zeros(SNAP_INTS, dtype=np.int64)
         dbls = np.zeros(SNAP_DBLS, dtype=np.float64)
@@ -207,6 +217,10 @@ class OracleEnv:
     def model_fallback_action(self, use_action_masking=True):
         """Env_3_Monolith.step(mode='model') without agents (env_monolith.py:186-221): the drawn flat action."""
         return int(self.L.orc_env_model_fallback_action(self._h, 1 if use_action_masking else 0))
+
+    def model_action(self, use_action_masking=True, draw_sort=True, draw_press=True):
+        """mode='model' with agents assigned: only the parts no agent decides are drawn (the other part is 0)."""
+        return int(self.L.orc_env_model_action(self._h, 1 if use_action_masking else 0, int(draw_sort), int(draw_press)))
 
     def trace_record(self):
         """The last step as one trace record (include/mse.h MSE_TRACE_* layout)."""

@@ -100,6 +100,33 @@ class ScriptedSortAgent:
         return int(self.next_mode), None
 
 
+class ScriptedPressAgent:
+    """Stands where Env_3_Monolith.step(mode='model') expects a trained pressing agent (env_monolith.py:198-210).
+    predict() records what it was handed - the observation and, if the env passed one, the action mask - and returns
+    `decide(mask)`: the next scripted press action."""
+
+    def __init__(self, decide):
+        self.decide = decide
+        self.last_obs = None
+        self.last_mask = None
+
+    def predict(self, obs, deterministic=True, action_masks=None):
+        self.last_obs = np.asarray(obs, dtype=np.float32).copy()
+        self.last_mask = None if action_masks is None else np.asarray(action_masks, dtype=np.uint8).copy()
+        return int(self.decide(self.last_mask)), None
+
+
+class MaskableScriptedPressAgent(ScriptedPressAgent):
+    """The same agent in the shape the reference's `is_maskable` test looks for (env_monolith.py:201: a `policy`
+    attribute and 'Maskable' in the type's name): the env then passes press_action_masks() to predict()."""
+    policy = object()
+
+
+class ScriptedMonoAgent(ScriptedPressAgent):
+    """Stands where Env_3_Monolith.step expects a stored monolith agent (env_monolith.py:144-150): predict(obs,
+    deterministic=True, action_masks=mask) -> flat action."""
+
+
 def _rng_words(gen) -> list[int]:
     st = gen.bit_generator.state
     s, inc = int(st["state"]["state"]), int(st["state"]["inc"])

@@ -1,7 +1,10 @@
 """Env-index sharding over the GPUs of one node: one process per GPU, each with its
 own handle; env instances never interact, so stepping needs no collective.  The only exchange is the
-rollout-buffer hand-off to the learner: ONE all-gather per rollout tensor over RCCL / xGMI, issued on a
-side stream so that it overlaps the next rollout's stepping.
+rollout-buffer hand-off to the learner: ONE collective per rollout tensor over RCCL / xGMI, issued on a
+side stream so that it overlaps the next rollout's stepping - an all-gather (every rank ends up with the whole
+rollout: data-parallel learners) or a gather to the learner rank (`mode="gather"`: only rank `dst` allocates the
+staging tensors and receives; at 2 M envs the all-gather would deliver 8 x 620 MB per 16-step rollout to every
+rank where one rank needs them).
 
 Rank r of R owns global envs [r*n_local, (r+1)*n_local); env g is seeded with base_seed + g and its
 policy stream is keyed by g, so the concatenation of all shards equals a single-handle run bit for bit
@@ -57,7 +60,10 @@ class RolloutExchange:
     """
 
     def __init__(self, group=None, device: Optional[torch.device] = None, side_stream: bool = True,
-                 force_collective: bool = False):
+                 force_collective: bool = False, mode: str = "allgather", dst: int = 0):
+        if mode not in ("allgather", "gather"):
+            raise ValueError("mode must be 'allgather' or 'gather'")
+        self.mode, self.dst = mode, int(dst)
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -67,6 +73,7 @@ class RolloutExchange:
         if side_stream and device is not None and device.type == "cuda":
             self.stream = torch.cuda.Stream(device=device)
         self._staging = [dict(), dict()]  # two sets of gathered tensors, keyed by rollout key
+        self._consumers = [None, None]    # per staging set: the stream that last consumed its result (wait / release)
         self._turn = 0
         self._pending = None
         self.sizes = None                 # per-rank env counts (set by the first gather)
@@ -90,6 +97,10 @@ class RolloutExchange:
             local = padded
         if not self.collective:
             out[0].copy_(local)
+        elif self.mode == "gather":
+            # rank-major staging on the learner only: out[r] is rank r's contiguous [K, n_max, ...] block
+            dist.gather(local.contiguous(), [out[r] for r in range(out.shape[0])] if out is not None else None,
+                        dst=self.dst if self.group is None else dist.get_global_rank(self.group, self.dst), group=self.group)
         else:
             dist.all_gather_into_tensor(out.view((-1,) + tuple(out.shape[2:])), local.contiguous(), group=self.group)
 
@@ -102,12 +113,21 @@ class RolloutExchange:
             sizes = self._sizes(local.shape[1], local.device)
             n_max = max(sizes)
             shape = (len(sizes), local.shape[0], n_max) + tuple(local.shape[2:])
+            if self.collective and self.mode == "gather" and self.rank != self.dst:
+                self._gather_into(None, local, n_max)   # a sender: no staging, no result
+                result[key] = None
+                continue
             out = staging.get(key)
             if out is None or tuple(out.shape) != shape or out.dtype != local.dtype or out.device != local.device:
                 out = staging[key] = torch.empty(shape, dtype=local.dtype, device=local.device)
             self._gather_into(out, local, n_max)
             result[key] = out
         return result
+
+    @property
+    def receives(self) -> bool:
+        """Does this rank end up with the gathered rollout?  (every rank with 'allgather', rank `dst` with 'gather')"""
+        return not (self.collective and self.mode == "gather" and self.rank != self.dst)
 
     # -- blocking ---------------------------------------------------------------------------------------------
     def gather_rollout(self, buffers: Dict[str, Optional[torch.Tensor]], layout: str = "rank_major"):
@@ -117,14 +137,26 @@ class RolloutExchange:
         self._turn ^= 1
         out = self._gather_set(buffers, self._staging[self._turn])
         if layout == "step_major":
+            if not self.receives:
+                return {k: None for k in out}
             ragged = len(set(self.sizes)) > 1
             return {k: (None if v is None else to_step_major(v, self.sizes if ragged else None)) for k, v in out.items()}
         return out
 
     # -- overlapped -------------------------------------------------------------------------------------------
     class Ticket:
-        def __init__(self, result, read_done, stream):
+        def __init__(self, result, read_done, stream, exchange=None, turn=0):
             self.result, self.read_done, self.stream = result, read_done, stream
+            self._exchange, self._turn = exchange, turn
+
+        def release(self, stream=None):
+            """Names the stream that consumes `result` (default: the current one).  The staging set is reused by the
+            call after next; that gather is then ordered behind everything `stream` has been given up to that moment.
+            `wait()` registers the caller's current stream by itself - call release() only when the result is read
+            on another stream."""
+            if self._exchange is not None and self.stream is not None:
+                self._exchange._consumers[self._turn] = stream if stream is not None else \
+                    torch.cuda.current_stream(self._exchange.device)
 
     def gather_rollout_async(self, buffers: Dict[str, Optional[torch.Tensor]]) -> "RolloutExchange.Ticket":
         """Starts the gather of `buffers` on the side stream; see the class docstring for the buffer contract."""
@@ -138,6 +170,14 @@ class RolloutExchange:
         filled = torch.cuda.Event()
         filled.record(cur)                       # the rollout that wrote `buffers`
         self.stream.wait_event(filled)
+        consumer = self._consumers[self._turn]
+        if consumer is not None:
+            # this staging set held the result of the call before last: whatever its consumer's stream has been given
+            # so far (its reads of that result, in program order) must finish before the gather overwrites the set
+            consumed = torch.cuda.Event()
+            consumed.record(consumer)
+            self.stream.wait_event(consumed)
+            self._consumers[self._turn] = None
         with torch.cuda.stream(self.stream):
             result = self._gather_set(buffers, staging)
             read_done = torch.cuda.Event()
@@ -145,7 +185,7 @@ class RolloutExchange:
         for v in buffers.values():
             if v is not None:
                 v.record_stream(self.stream)     # the allocator must not recycle them under the gather
-        t = RolloutExchange.Ticket(result, read_done, self.stream)
+        t = RolloutExchange.Ticket(result, read_done, self.stream, self, self._turn)
         self._pending = t
         return t
 
@@ -160,6 +200,7 @@ class RolloutExchange:
             for v in t.result.values():
                 if v is not None:
                     v.record_stream(cur)         # allocated on the side stream, consumed on this one
+            t.release(cur)                       # the set's next reuse waits for this stream's reads
         if t is self._pending:
             self._pending = None
         return t.result
@@ -174,7 +215,7 @@ class ShardedSortingEnv:
 
     def __init__(self, global_envs: int, kind: str = "mono", base_seed: int = 0, group=None,
                  device: Optional[torch.device] = None, make_env: Optional[Callable] = None,
-                 force_collective: bool = False, **env_kw):
+                 force_collective: bool = False, exchange_mode: str = "allgather", learner_rank: int = 0, **env_kw):
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.global_envs = int(global_envs)
@@ -190,7 +231,8 @@ class ShardedSortingEnv:
             device = dev
         self.device = device
         self.env = make_env(self.n_local, self.start)
-        self.exchange = RolloutExchange(group=group, device=device, force_collective=force_collective)
+        self.exchange = RolloutExchange(group=group, device=device, force_collective=force_collective,
+                                        mode=exchange_mode, dst=learner_rank)
         self.equal_shards = self.global_envs % self.world == 0
         self._sets = [None, None]    # ping-pong local rollout buffers of rollout_async
         self._tickets = [None, None]

@@ -48,6 +48,24 @@ def test_side_stream_exchange_equals_blocking_gather():
         got = sh.collect(prev[1])
         assert torch.equal(got["obs"][0], expect[rounds - 1]["obs"])
         assert checked == rounds - 1
+        # gather-to-learner (dist.gather into the learner's rank-major staging), same overlap, same tensors; the
+        # consumer reads on a stream of its own and says so (Ticket.release)
+        shg = ShardedSortingEnv(n, device=dev, force_collective=True, exchange_mode="gather", learner_rank=0, **kw)
+        assert shg.exchange.receives
+        reader = torch.cuda.Stream(device=dev)
+        prev, sums = None, []
+        for it in range(rounds):
+            ticket = shg.rollout_async(K, policy_seed=9)
+            if prev is not None:
+                got = shg.collect(prev[1])
+                reader.wait_stream(torch.cuda.current_stream(dev))
+                with torch.cuda.stream(reader):
+                    sums.append((prev[0], got["obs"].double().sum(), got["actions"].long().sum()))
+                prev[1].release(reader)
+            prev = (it, ticket)
+        torch.cuda.synchronize(dev)
+        for it, so, sa in sums:
+            assert float(so) == float(expect[it]["obs"].double().sum()) and int(sa) == int(expect[it]["actions"].long().sum()), it
         # the blocking path gives the same tensors in the single-handle layout
         ref2 = M.BatchedSortingEnv(num_envs=n, device=dev, **kw)
         sh2 = ShardedSortingEnv(n, device=dev, force_collective=True, **kw)

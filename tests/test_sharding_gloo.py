@@ -73,6 +73,25 @@ def _worker(rank, world, port, global_envs, k, ok):
         for tk, seed in ((t1, 5), (t2, 6)):
             out = ex.wait(tk)
             assert torch.equal(to_step_major(out["obs"], sizes), FakeEnv(global_envs, 0).rollout(k, policy_seed=seed)["obs"])
+        # gather-to-learner: only rank `dst` receives (and allocates) the rank-major rollout; the others just send
+        for dst in (0, world - 1):
+            shg = ShardedSortingEnv(global_envs, make_env=lambda n, off: FakeEnv(n, off), device=torch.device("cpu"),
+                                    exchange_mode="gather", learner_rank=dst)
+            rm = shg.rollout(k, policy_seed=4, layout="rank_major")
+            sm = shg.rollout(k, policy_seed=4)
+            exp4 = FakeEnv(global_envs, 0).rollout(k, policy_seed=4)
+            assert shg.exchange.receives == (rank == dst)
+            if rank == dst:
+                for key in exp4:
+                    assert torch.equal(to_step_major(rm[key], shg.exchange.sizes), exp4[key]), key
+                    assert torch.equal(sm[key], exp4[key]), key
+            else:
+                assert all(v is None for v in rm.values()) and all(v is None for v in sm.values())
+                assert not any(shg.exchange._staging)          # a sender holds no staging memory
+            tk = shg.exchange.gather_rollout_async(FakeEnv(shg.n_local, shg.start).rollout(k, policy_seed=8))
+            out = shg.exchange.wait(tk)
+            if rank == dst:
+                assert torch.equal(to_step_major(out["reward"], shg.exchange.sizes), FakeEnv(global_envs, 0).rollout(k, policy_seed=8)["reward"])
         ok[rank] = 1
     finally:
         dist.barrier()

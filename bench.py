@@ -131,7 +131,9 @@ def kernel_name(kind, n, policy, pipeline, mode, cus=256):
         return "k_sample + k_step"
     if policy == "mlp":
         return "k_rollout_policy"
-    return {1: "k_rollout_po", 2: "k_rollout", 3: "k_rollout_ring"}.get(pipeline, "k_rollout_ring" if n <= 256 * cus else "k_rollout")
+    wgs = -(-n // 256)   # the library's rule (mse_create): one round of 256-env workgroups, or most of a second one
+    by_size = wgs <= cus or (cus + cus // 4 < wgs <= 2 * cus)
+    return {1: "k_rollout_po", 2: "k_rollout", 3: "k_rollout_ring"}.get(pipeline, "k_rollout_ring" if by_size else "k_rollout")
 
 
 class Workload:

@@ -99,9 +99,10 @@ typedef struct mse_config {
     /* seasonal patterns 1 and 2, order A,B,C,D (utils/input_generator.py:17-20) */
     double   pattern_ratio[2][4];
     /* mse_rollout kernel choice: 0 = by size (while the batch fits the chip in one round of 256-env workgroups,
-       n <= 256 x CUs, the multi-role kernels: dynamics + observer waves, plus RNG waves when the config's draws per
-       step fit the ring; above, one lane per env), 1 = dynamics + observer waves, 2 = one lane per env,
-       3 = dynamics + observer + RNG waves.  Results are identical. */
+       n <= 256 x CUs - or fills most of a second one, 320 x CUs < n <= 512 x CUs -, the multi-role kernels:
+       dynamics + observer waves, plus RNG waves when the config's draws per step fit the ring; otherwise one lane
+       per env), 1 = dynamics + observer waves, 2 = one lane per env, 3 = dynamics + observer + RNG waves.
+       Results are identical. */
     int32_t  rollout_pipeline;
     int32_t  reserved0;
 } mse_config;

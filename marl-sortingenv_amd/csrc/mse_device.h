@@ -89,6 +89,10 @@ struct Params {
     uint32_t qi_down[4]; // bit q set: int((q / 100.0) * 100.0) == q - 1  (press_bale's stored quality)
     int rem_thr_units;   // floor(bale_standard_size * bale_remainder_threshold)
     int ring_worst; // most sort_material draws one step can make with this config (k_rollout_ring flow control)
+    // the LCG's jump FORWARD by ring_worst steps, s' = A s + G inc (A_lo, A_hi, G_lo, G_hi): the two halves of the
+    // ring's priming are that far apart (k_rollout_ring); kernel arguments because the observer lanes need them
+    // before the table image is in LDS
+    uint64_t ring_fwd[4];
     // General generator mode (utils/input_generator.py:46-61 with a floor() remainder, e.g. input_batch_size 90): the stage
     // vectors are carried as their packed counts instead of pattern ids, the generator's private stream runs on the
     // device (remainder draws + the shuffle's draws), and only the one-lane kernels serve the handle.
@@ -718,15 +722,20 @@ __device__ __forceinline__ void pcg_jump(Pcg &g, uint32_t n, const uint64_t *jum
 // of k_rollout_ring end a launch at most 64 (usually < `worst`) outputs ahead of what the env consumed and hand the
 // stream back this way.
 constexpr int kRingBackSteps = 33;
-__device__ __forceinline__ void pcg_step_back(Pcg &g, uint32_t d, const uint64_t *back_tab)
+// s' = A s + G inc (mod 2^128): any number of LCG steps, forward or back, in two 128-bit multiplies
+__device__ __forceinline__ void pcg_affine(Pcg &g, uint64_t a_lo, uint64_t a_hi, uint64_t g_lo, uint64_t g_hi)
 {
-    const uint64_t *t = back_tab + 4 * d; // d <= 32
     uint64_t x_lo, x_hi, y_lo, y_hi;
-    mul128(t[0], t[1], g.s_lo, g.s_hi, x_lo, x_hi);
-    mul128(t[2], t[3], g.i_lo, g.i_hi, y_lo, y_hi);
+    mul128(a_lo, a_hi, g.s_lo, g.s_hi, x_lo, x_hi);
+    mul128(g_lo, g_hi, g.i_lo, g.i_hi, y_lo, y_hi);
     const uint64_t lo = x_lo + y_lo;
     g.s_hi = x_hi + y_hi + (lo < x_lo ? 1ull : 0ull);
     g.s_lo = lo;
+}
+__device__ __forceinline__ void pcg_step_back(Pcg &g, uint32_t d, const uint64_t *back_tab)
+{
+    const uint64_t *t = back_tab + 4 * d; // d <= 32
+    pcg_affine(g, t[0], t[1], t[2], t[3]);
 }
 
 // the lane advances the env's own generator

@@ -699,6 +699,8 @@ struct RingLayout {
     static constexpr int table_offset = pos_offset + pos_bytes; // multiple of 16
 };
 
+constexpr int kRingTwoHalvesFrom = 16; // launches this long prime the ring in two halves (RNG + observer lanes)
+
 template <int KIND, bool NOISE>
 __global__ __launch_bounds__(kRingThreads) void k_rollout_ring(Params P, uint4 *__restrict__ planes,
                                                                const uint32_t *__restrict__ table_image, int k_steps,
@@ -742,12 +744,36 @@ __global__ __launch_bounds__(kRingThreads) void k_rollout_ring(Params P, uint4 *
         load_env_raw<KIND, NOISE>(raw, planes, P, i);
         if (KIND == 2 && sort_mode != nullptr) sm = sort_mode[i];
     }
-    if (role != 2) {
+    if (role == 0) {
         TableCopy<2 * kPoEnvs, 2> tc;
         tc.issue(table_image, P.table_words, tid);
         tc.commit(ltab, table_image, P.table_words, tid);
+        unpack_env<KIND, NOISE>(e, raw, P);
+    } else if (role == 1) {
+        // The observer lanes have nothing to observe before the first snapshot: they prime the second half of the
+        // ring (see the RNG waves below) - outputs [worst, 2 worst) of their env's stream, reached by one jump - while
+        // their share of the table image is in flight, and write that to LDS afterwards.
+        uint4 ps = {}, pi = {};
+        const bool two_halves = k_steps >= kRingTwoHalvesFrom;
+        if (two_halves) {
+            ps = planes[PL_RNG_STATE * P.n_pad + i];
+            pi = planes[PL_RNG_INC * P.n_pad + i];
+        }
+        TableCopy<2 * kPoEnvs, 2> tc;
+        tc.issue(table_image, P.table_words, tid);
+        if (two_halves) {
+            Pcg g;
+            g.s_lo = (uint64_t)ps.x | ((uint64_t)ps.y << 32);
+            g.s_hi = (uint64_t)ps.z | ((uint64_t)ps.w << 32);
+            g.i_lo = (uint64_t)pi.x | ((uint64_t)pi.y << 32);
+            g.i_hi = (uint64_t)pi.z | ((uint64_t)pi.w << 32);
+            pcg_affine(g, P.ring_fwd[0], P.ring_fwd[1], P.ring_fwd[2], P.ring_fwd[3]);
+            uint32_t w2 = (uint32_t)P.ring_worst;
+            ring_produce(g, w2, (uint32_t)P.ring_worst,
+                         (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)(lring + el));
+        }
+        tc.commit(ltab, table_image, P.table_words, tid);
     }
-    if (role == 0) unpack_env<KIND, NOISE>(e, raw, P);
     MSE_TL(edge, 0); // state loads and the table image -> LDS
 
     if (role == 2) {
@@ -770,6 +796,14 @@ __global__ __launch_bounds__(kRingThreads) void k_rollout_ring(Params P, uint4 *
         // the per-step spread (6 or 19 draws with the default config) towards the long-run mean.
         const uint32_t worst = (uint32_t)P.ring_worst;
         uint32_t w = 0, need = worst, cap = need; // step 0's outputs, in place before B_init
+        // The ring is primed in two halves: this lane produces outputs [0, worst) and, in parallel on the same SIMD,
+        // the env's OBSERVER lane - idle until the first snapshot - produces [worst, 2 worst) from a state it reaches
+        // by one table-driven jump.  At B_init the ring then holds what B_0 asks for (r_{-1} + 2 worst), so step 0
+        // does not wait for a second round of production; this lane jumps over the observer's half after B_init.
+        // The deeper start also smooths the wave's per-step production for the rest of the launch.  Same-box T(K): the
+        // observer's half ends ~0.7 us after this lane's, paid back from K = 16 on (K = 2: +0.75 us, 16-20: equal,
+        // 32: -0.8 %, 64: -1.2 %), hence only for launches of kRingTwoHalvesFrom steps or more.
+        const bool two_halves = k_steps >= kRingTwoHalvesFrom;
 #ifdef MSE_TIMELINE
         Timeline tl;
         tl.start();
@@ -789,6 +823,10 @@ __global__ __launch_bounds__(kRingThreads) void k_rollout_ring(Params P, uint4 *
             MSE_TLB(tl, 0);
             lds_barrier_all(); // s == -1: B_init (first outputs are in place); else B_s
             MSE_TLB(tl, 1);
+            if (s < 0 && two_halves) {
+                pcg_affine(g, P.ring_fwd[0], P.ring_fwd[1], P.ring_fwd[2], P.ring_fwd[3]); // + worst
+                w += worst;
+            }
             const uint32_t steps_left = (uint32_t)(k_steps - 1 - s); // steps s+1 .. K-1
             const uint32_t r = lpos[el];                             // 0 at B_init
             const uint32_t ahead = worst * steps_left;
@@ -1877,6 +1915,23 @@ static bool ring_kernels_static_lds_free()
     return cached == 1;
 }
 
+// Params::ring_fwd: s_{n+d} = M^d s_n + (1 + M + ... + M^{d-1}) inc for d = ring_worst, the distance between the two
+// halves of the ring's priming (k_rollout_ring)
+static void set_ring_forward_jump(Params &P)
+{
+    typedef unsigned __int128 u128;
+    const u128 M = (((u128)0x2360ED051FC65DA4ull) << 64) | (u128)0x4385DF649FCCF645ull;
+    u128 A = 1, G = 0;
+    for (int d = 0; d < P.ring_worst; ++d) {
+        G = G + A;
+        A = A * M;
+    }
+    P.ring_fwd[0] = (uint64_t)A;
+    P.ring_fwd[1] = (uint64_t)(A >> 64);
+    P.ring_fwd[2] = (uint64_t)G;
+    P.ring_fwd[3] = (uint64_t)(G >> 64);
+}
+
 template <int KIND>
 static void launch_rollout(mse_env *h, hipStream_t s, int k_steps, uint64_t policy_seed, const int32_t *sort_mode,
                            uint32_t flags, int32_t *actions, float *obs, float *rew, uint8_t *done, uint8_t *mask)
@@ -2134,8 +2189,12 @@ int mse_create_indexed(mse_env **out, const mse_config *cfg, int64_t n_envs, int
             cus = prop.multiProcessorCount;
     }
     h->cus = cus;
-    h->pipelined = cfg->rollout_pipeline == 1 || cfg->rollout_pipeline == 3 ||
-                   (cfg->rollout_pipeline == 0 && n_envs <= (int64_t)kPoEnvs * cus);
+    // ... and again while it fills most of a SECOND round: same-box at 64 steps per launch, three-role kernel against
+    // one lane per env: 98 304 envs 17.5 G against 15.5, 131 072 envs 22.9 against 20.5 (two full rounds run at the
+    // one-round rate; the one-lane grid has only two waves per SIMD there), 196 608 envs 23.1 against 23.8
+    const int64_t n_wg = (n_envs + kPoEnvs - 1) / kPoEnvs;
+    const bool by_size = n_wg <= cus || (n_wg > cus + cus / 4 && n_wg <= 2 * (int64_t)cus);
+    h->pipelined = cfg->rollout_pipeline == 1 || cfg->rollout_pipeline == 3 || (cfg->rollout_pipeline == 0 && by_size);
     if (P.gen_mode) { // general generator mode: the multi-role kernels carry stage ids, not counts
         if (cfg->rollout_pipeline == 1 || cfg->rollout_pipeline == 3) {
             delete h;
@@ -2177,7 +2236,10 @@ int mse_create_indexed(mse_env **out, const mse_config *cfg, int64_t n_envs, int
         else if (cfg->env_kind == MSE_ENV_PRESS) ring_lds += nz ? RingLayout<2, true>::table_offset : RingLayout<2, false>::table_offset;
         else ring_lds += nz ? RingLayout<3, true>::table_offset : RingLayout<3, false>::table_offset;
         P.ring_worst = worst;
+        set_ring_forward_jump(P);
         const bool fits = worst <= kRingMaxPerStep && !h->literal && ring_lds <= (size_t)160 * 1024 && ring_kernels_static_lds_free();
+        // (the second-round rule above was measured with the three-role kernel only)
+        if (cfg->rollout_pipeline == 0 && n_wg > cus && !fits) h->pipelined = false;
         h->ring = h->pipelined && fits && cfg->rollout_pipeline != 1;
         if (cfg->rollout_pipeline == 3 && !fits) {
             delete h; // nothing is allocated on the device yet

@@ -19,8 +19,9 @@ lib = os.path.abspath(sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "
 kind = sys.argv[2] if len(sys.argv) > 2 else "mono"
 n = int(sys.argv[3]) if len(sys.argv) > 3 else 65536
 K = int(sys.argv[4]) if len(sys.argv) > 4 else 16
+noise = float(sys.argv[5]) if len(sys.argv) > 5 else 0.0
 launches = 13
-env = M.BatchedSortingEnv(kind=kind, num_envs=n, device=0, base_seed=0, max_steps=200, noise_sorting=0.0,
+env = M.BatchedSortingEnv(kind=kind, num_envs=n, device=0, base_seed=0, max_steps=200, noise_sorting=noise,
                           balesize=200, library=lib)
 buf = env.alloc_rollout(K)
 L = env.L
@@ -43,7 +44,7 @@ names = {
     1: ["barrier wait", "snap read+observe", "stage+store", "", "", "", "", ""],
     2: ["produce", "barrier wait", "", "", "", "", "", ""],
 }
-print(f"{kind} {n} envs: {ms * 1e3:.1f} us per launch of {K} steps = {ms * 1e3 / K:.2f} us/step (instrumented build)")
+print(f"{kind} {n} envs noise {noise}: {ms * 1e3:.1f} us per launch of {K} steps = {ms * 1e3 / K:.2f} us/step (instrumented build)")
 ev = [out[24 + k] / (4 * launches) for k in range(6)]
 print("  launch edges (dynamics wave, ticks per launch): " + ", ".join(
     f"{nm} {v:.0f}" for nm, v in zip(["tables->LDS", "state load", "ring priming wait", "step loop", "jump-ahead", "state store"], ev)))

@@ -262,9 +262,10 @@ int mse_error_count(mse_env *env, uint64_t *count_out);
 /* Algorithmic HBM bytes per env-step used for the roofline figure. */
 int mse_algorithmic_bytes_per_step(const mse_env *env);
 
-/* Build constant: a `choice` draw whose 32-bit fraction view f satisfies f + 0x200 < window is decided by the
- * literal fp64 cdf instead of the exact integer comparison (DESIGN.md "choice").  0x210 in the shipped
- * library; the test-only build libmse_hip_widetie.so reports 0x08000000. */
+/* Build constant: a `choice` draw whose 32-bit fraction view f satisfies f + 160 < window (32-bit wrap-around: f below
+ * window - 160, or within 160 of 2^32) is decided by the literal fp64 cdf instead of the exact integer comparison
+ * (DESIGN.md "choice"; the derivation of the margin is in csrc/mse_device.h).  162 in the shipped library; the
+ * test-only build libmse_hip_widetie.so reports 0x08000000. */
 uint32_t mse_tie_window(void);
 
 /* ---- the policy on the caller's side of step() -----------------------------------------------

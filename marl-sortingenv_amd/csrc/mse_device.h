@@ -806,12 +806,24 @@ struct RngCounted {
 // <= 2^-49 of rounding); v = floor(u*T) and a 32-bit view f of the fraction come from (r >> 32) * T.
 // Byte k of D = (0x80 + v) - c_k keeps bit 7 iff c_k <= v; the chosen bin is the first k with c_k > v and
 // removing one unit there lowers every prefix sum from k on by one: C += (flags >> 7) - 0x01010101.
-// If f is within a wide margin of 0 or 2^32 the literal fp64 path decides instead (DESIGN.md "choice").
-// A draw is "near a tie" when f + 0x200 < MSE_TIE_WINDOW, i.e. f < 16 or f >= 2^32 - 512 with the shipped
-// window.  libmse_hip_widetie.so (tests only) is the same source with a window ~10^5 times wider, so that the
-// literal branches run on a few percent of the draws and are held to the same golden vectors.
+// If f is within a margin of 0 or 2^32 the literal fp64 path decides instead (DESIGN.md "choice").
+//
+// How wide the margin must be.  r >> 11 = r_hi 2^21 + eps with r_hi = r >> 32 and eps < 2^21 the next 21 bits, so in
+// units of 2^-32:  u T = r_hi T + delta,  delta = eps T / 2^21 in [0, T), T <= 127:  floor(u T) = v unless
+// f + delta >= 2^32, which needs f >= 2^32 - 127.  The fp64 cdf is within 6 x 2^-53 of c_k / T (one division, up to
+// three additions, one division by cdf[-1] <= 1), i.e. within 2^-11.4 of these units after the scaling by T: it can only
+// disagree with the exact comparison when f + delta < 2^-11 (so f = 0) or f + delta > 2^32 - 2^-11 (so f >= 2^32 - 128).
+// A draw is "near a tie" when f + MSE_TIE_HI < MSE_TIE_WINDOW (32-bit wrap-around): f < MSE_TIE_WINDOW - MSE_TIE_HI
+// (= 2 as shipped: f = 0 with a margin of one) or f >= 2^32 - MSE_TIE_HI (= 160: the 128 with a margin of 32), once in
+// 2.6 x 10^7 draws.  Round 2 shipped 16 / 512 (once in 8 x 10^6): at 65 536 envs a 20-step launch met ~2 such draws, and
+// the workgroup that redoes a step held the whole launch back by 6 us (tools/clock_probe.py: 9 % of a 20-step launch).
+// libmse_hip_widetie.so (tests only) is the same source with MSE_TIE_WINDOW = 2^27, so that the literal branches run on
+// a few percent of the draws and are held to the same golden vectors.
+#ifndef MSE_TIE_HI
+#define MSE_TIE_HI 160u
+#endif
 #ifndef MSE_TIE_WINDOW
-#define MSE_TIE_WINDOW 0x210u
+#define MSE_TIE_WINDOW (MSE_TIE_HI + 2u)
 #endif
 
 template <bool LITERAL, class RNG>
@@ -829,7 +841,7 @@ __device__ __forceinline__ void draw_units(RNG &rng, uint32_t &C, int &rem)
             const uint32_t f = (uint32_t)prod;
             const uint32_t v = (uint32_t)(prod >> 32);
             flags = ((__umul24(v, 0x010101u) | 0x00808080u) - C) & 0x00808080u; // bytes 0..2 only; v < 128
-            literal = (f + 0x200u) < MSE_TIE_WINDOW;
+            literal = (f + MSE_TIE_HI) < MSE_TIE_WINDOW;
         }
         if (__builtin_expect(literal, 0)) { // ~1e-7 per draw: keep it out of the loop's straight line
             const int sel = choice4_literal(C, rng.last_full());
@@ -1145,10 +1157,16 @@ __device__ __forceinline__ void sort_material(Env &e, RngRing &rng, uint32_t sor
     station_pair_ring<0>(e, rng, C, acc_sorter);
     station_pair_ring<2>(e, rng, C, acc_sorter);
     e.ce += (int)(C >> 24);
-    // near a tie: f < window - 0x200 or f >= 2^32 - 0x200  (f + 0x200 < window, as in draw_units)
-    if (__builtin_expect(rng.f_min < MSE_TIE_WINDOW - 0x200u || rng.f_max >= 0xFFFFFE00u, 0)) {
-        // some draw of this step sat within the margin of a cdf boundary: take the step again from the
-        // saved counters with every decision made by the literal fp64 cdf on the full 64-bit outputs
+    // near a tie: f < window - hi or f >= 2^32 - hi  (f + hi < window, as in draw_units)
+#ifdef MSE_ABL_NOTIE // (ablation timing builds only: near ties are never looked at - results can differ)
+    if (false) {
+#else
+    if (__builtin_expect(rng.f_min < MSE_TIE_WINDOW - MSE_TIE_HI || rng.f_max >= 0u - MSE_TIE_HI, 0)) {
+#endif
+        // some draw of this step sat within the margin of a cdf boundary: take the step again from the saved counters
+        // on the full 64-bit outputs of a generator positioned by jump-ahead, every draw decided as draw_units<false>
+        // decides it - the exact integer comparison, and the literal fp64 cdf for the draw(s) inside the margin (the
+        // whole workgroup waits for this lane: every fp64 cdf that need not be evaluated is 8 divisions saved)
         e.ct[0] = ct0; e.ct[1] = ct1; e.ct[2] = ct2; e.ct[3] = ct3;
         e.cf[0] = cf0; e.cf[1] = cf1; e.cf[2] = cf2; e.cf[3] = cf3;
         e.ce = ce0;
@@ -1156,7 +1174,7 @@ __device__ __forceinline__ void sort_material(Env &e, RngRing &rng, uint32_t sor
         exact.g = rng.start;
         exact.count = 0;
         pcg_jump(exact.g, p10_0 >> 10, rng.jump_tab);
-        sort_material<true>(e, exact, sorting_word, acc_sorter);
+        sort_material<false>(e, exact, sorting_word, acc_sorter);
         rng.p10 = p10_0 + (exact.count << 10);
     }
 }
@@ -1190,13 +1208,15 @@ __device__ __forceinline__ void sort_material_local_fast(Env &e, Pcg &g, uint32_
     station_pair_local<0>(e, g, C, acc_sorter, f_min, f_max);
     station_pair_local<2>(e, g, C, acc_sorter, f_min, f_max);
     e.ce += (int)(C >> 24);
-    if (__builtin_expect(f_min < MSE_TIE_WINDOW - 0x200u || f_max >= 0xFFFFFE00u, 0)) {
+    if (__builtin_expect(f_min < MSE_TIE_WINDOW - MSE_TIE_HI || f_max >= 0u - MSE_TIE_HI, 0)) {
         e.ct[0] = ct0; e.ct[1] = ct1; e.ct[2] = ct2; e.ct[3] = ct3;
         e.cf[0] = cf0; e.cf[1] = cf1; e.cf[2] = cf2; e.cf[3] = cf3;
         e.ce = ce0;
-        g = g0;
-        RngLocal exact{g};
-        sort_material<true>(e, exact, sorting_word, acc_sorter);
+        RngCounted exact; // the structured loop: integer decisions, the literal cdf for the draw(s) inside the margin
+        exact.g = g0;
+        exact.count = 0;
+        sort_material<false>(e, exact, sorting_word, acc_sorter);
+        g = exact.g;
     }
 }
 
@@ -1758,7 +1778,9 @@ __device__ __forceinline__ void env_dynamics(Env &e, RNG &rng, const Params &P, 
             }
         }
     }
+#ifndef MSE_ABL_NOPRESS // (ablation timing builds only: tools/ablate.sh)
     if (run_press_rules) press_action_rules<TRACE, BALES>(e, P, tb.press_time, press_action, bales, lg);
+#endif
     MSE_TL(e.tl, 3);
 
     // snapshot for the observer

@@ -701,6 +701,10 @@ struct RingLayout {
 
 constexpr int kRingTwoHalvesFrom = 16; // launches this long prime the ring in two halves (RNG + observer lanes)
 
+#ifdef MSE_CLOCK_PROBE
+__device__ unsigned long long g_clock_probe[3]; // shader cycles, 100 MHz ticks, launches (workgroup 0 of k_rollout_ring)
+__device__ unsigned long long g_wg_probe[3 * 1024]; // per workgroup of the LAST launch: start, end (100 MHz ticks), XCC id
+#endif
 template <int KIND, bool NOISE>
 __global__ __launch_bounds__(kRingThreads) void k_rollout_ring(Params P, uint4 *__restrict__ planes,
                                                                const uint32_t *__restrict__ table_image, int k_steps,
@@ -731,6 +735,9 @@ __global__ __launch_bounds__(kRingThreads) void k_rollout_ring(Params P, uint4 *
 #ifdef MSE_TIMELINE
     Timeline edge;
     edge.start();
+#endif
+#ifdef MSE_CLOCK_PROBE // diagnostic build only (tools/clock_probe.py): shader cycles and 100 MHz ticks of one wave's launch
+    const unsigned long long probe_c0 = __builtin_readcyclecounter(), probe_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
 
     // Launch prologue, overlapped: the RNG waves start priming the ring at once (they never read a table before
@@ -819,7 +826,11 @@ __global__ __launch_bounds__(kRingThreads) void k_rollout_ring(Params P, uint4 *
                 if (__builtin_amdgcn_ballot_w64(deficit >= cand) != 0ull) M = cand;
             }
             const uint32_t room = cap > w ? cap - w : 0u;
+#ifdef MSE_ABL_NORNG // (ablation timing builds only: the ring holds garbage, the stream is not advanced)
+            w += M < room ? M : room;
+#else
             ring_produce(g, w, M < room ? M : room, ring_lane_addr);
+#endif
             MSE_TLB(tl, 0);
             lds_barrier_all(); // s == -1: B_init (first outputs are in place); else B_s
             MSE_TLB(tl, 1);
@@ -972,7 +983,11 @@ __global__ __launch_bounds__(kRingThreads) void k_rollout_ring(Params P, uint4 *
             sn.done = (int)((pk >> 23) & 1u);
             sn.overflowed = (int)((pk >> 24) & 1u);
             int k[4];
+#ifdef MSE_ABL_NOOBS // (ablation timing builds only: rows of zeros are staged and stored)
+            StepResult r{0.0, sn.done, 0.0, 0.0};
+#else
             StepResult r = env_observe<KIND, NOISE>(sn, P, tb, k, o);
+#endif
             if (__builtin_expect(sn.done != 0, 0)) { // the step's observation is the one after the auto-reset
                 Snap rs;
                 snap_of_reset(rs, tb.cst);
@@ -999,6 +1014,18 @@ __global__ __launch_bounds__(kRingThreads) void k_rollout_ring(Params P, uint4 *
         tl.flush(1);
 #endif
     }
+#ifdef MSE_CLOCK_PROBE
+    if (tid == kPoEnvs && blockIdx.x == 0) { // one observer lane: its wave is the last to finish
+        atomicAdd(&g_clock_probe[0], __builtin_readcyclecounter() - probe_c0);
+        atomicAdd(&g_clock_probe[1], __builtin_amdgcn_s_memrealtime() - probe_r0);
+        atomicAdd(&g_clock_probe[2], 1ull);
+    }
+    if (tid == kPoEnvs && blockIdx.x < 1024) {
+        g_wg_probe[3 * blockIdx.x] = probe_r0;
+        g_wg_probe[3 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+        g_wg_probe[3 * blockIdx.x + 2] = (unsigned long long)__builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20); // HW_REG_XCC_ID[3:0]
+    }
+#endif
 }
 
 
@@ -2034,6 +2061,22 @@ extern "C" {
 
 int mse_version(void) { return MSE_VERSION; }
 uint32_t mse_tie_window(void) { return MSE_TIE_WINDOW; }
+#ifdef MSE_CLOCK_PROBE
+// diagnostic build: read and clear {shader cycles, 100 MHz ticks, launches} of workgroup 0's launches
+int mse_debug_clock(unsigned long long *out3)
+{
+    unsigned long long zero[3] = {};
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(out3, HIP_SYMBOL(g_clock_probe), sizeof(zero)) != hipSuccess) return -1;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_clock_probe), zero, sizeof(zero)) != hipSuccess) return -1;
+    return 0;
+}
+int mse_debug_wg_probe(unsigned long long *out3072)
+{
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    return hipMemcpyFromSymbol(out3072, HIP_SYMBOL(g_wg_probe), sizeof(unsigned long long) * 3 * 1024) == hipSuccess ? 0 : -1;
+}
+#endif
 #ifdef MSE_TIMELINE
 // diagnostic build: read and clear the per-role section cycle sums (role-major, 8 sections each)
 int mse_debug_timeline(unsigned long long *out32)

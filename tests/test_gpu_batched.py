@@ -214,9 +214,11 @@ def test_ring_rollout_launch_boundaries_around_resets(kind):
 
 
 def test_long_run_near_ties_in_the_shipped_window():
-    """65 536 envs x 20 000 steps = 1.6e10 draws: with the shipped window (2^-23 of the draws) some 2 000 of them sit
-    near a cdf boundary, so the three-role kernel's whole-step literal redo and the one-lane kernel's per-draw
-    fallback both run for real - against the one-lane kernel with EVERY draw decided by the literal fp64 cdf.
+    """65 536 envs x 20 000 steps = 1.6e10 draws: with the shipped window (162 / 2^32 of the draws: f < 2 or
+    f >= 2^32 - 160, derived in csrc/mse_device.h) some 600 of them sit inside the margin of a cdf boundary, so the
+    three-role kernel's redo of a step on jump-ahead outputs and the one-lane kernel's redo both run for real - and the
+    ~1 400 draws that round 2's wider window (16 / 512) sent to the literal cdf are now decided by the integer comparison
+    - against the one-lane kernel with EVERY draw decided by the literal fp64 cdf.
     Rewards, dones, actions of every step and the final state (incl. PCG64 positions) must be identical."""
     import torch
 

@@ -23,7 +23,7 @@ def _wide_lib():
     assert os.path.exists(WIDE), "build libmse_hip_widetie.so first: python __graft_entry__.py"
     L = M.load_library(WIDE)
     assert L.mse_tie_window() == 0x08000000
-    assert M.load_library().mse_tie_window() == 0x210
+    assert M.load_library().mse_tie_window() == 162  # f < 2 or f >= 2^32 - 160 (csrc/mse_device.h)
     return WIDE
 
 

@@ -1005,6 +1005,114 @@ __device__ __forceinline__ void ring_produce(Pcg &g, uint32_t &w, uint32_t count
     w += count;
 }
 
+// Two outputs per iteration from ONE state: s_{n+1} = M s_n + inc and s_{n+2} = M^2 s_n + (M + 1) inc are independent
+// 128-bit multiplies of the same s_n by two constants, so the two LCG chains (and the two outputs' XSL-RR) interleave
+// instruction by instruction: 65 instructions per two outputs against 68 (one loop-control block instead of two), half
+// the dependent chain.  Same-box A/B: +1.2 % env-steps/s at 20 and at 64 steps per launch - what the three instructions
+// are worth; the shorter chain by itself is worth nothing (the SIMD's vector unit, not this wave's latency, is the limit:
+// DESIGN.md section 6).  `pairs` double steps; c2 = (M + 1) inc.
+// Chain A (-> outputs #w, #w+2, ...) works in v[112:127] and leaves its state in v[90:93]; chain B in v[94:109].
+__device__ __forceinline__ void ring_produce_pairs(Pcg &g, uint32_t &w, uint32_t pairs, uint32_t lane_addr, uint64_t c2_lo,
+                                                   uint64_t c2_hi)
+{
+    uint32_t s0 = (uint32_t)g.s_lo, s1 = (uint32_t)(g.s_lo >> 32), s2 = (uint32_t)g.s_hi, s3 = (uint32_t)(g.s_hi >> 32);
+    const uint32_t i0 = (uint32_t)g.i_lo, i1 = (uint32_t)(g.i_lo >> 32), i2 = (uint32_t)g.i_hi, i3 = (uint32_t)(g.i_hi >> 32);
+    const uint32_t j0 = (uint32_t)c2_lo, j1 = (uint32_t)(c2_lo >> 32), j2 = (uint32_t)c2_hi, j3 = (uint32_t)(c2_hi >> 32);
+    const uint32_t m0 = 0x9FCCF645u, m1 = 0x4385DF64u, m2 = 0x1FC65DA4u, m3 = 0x2360ED05u, kMask = 0xFC00u;
+    const uint32_t n0 = 0x20E0AE99u, n1 = 0x529ED9EBu, n2 = 0xDF69743Cu, n3 = 0x17BCE35Bu; // M^2 mod 2^128
+    uint32_t w10 = w << 10, left = pairs;
+    uint64_t sv, cm, dm;
+    asm volatile(
+        "s_mov_b64 %[sv], exec\n\t"
+        "v_cmp_ne_u32 vcc, 0, %[left]\n\t"
+        "s_and_b64 exec, exec, vcc\n\t"
+        "s_cbranch_execz 3f\n\t"
+        "v_mov_b32 v121, 0\n\t"
+        "v_mov_b32 v109, 0\n"
+        "1:\n\t"
+        "v_mad_u64_u32 v[112:113], %[dm], %[s0], %[m0], 0\n\t"
+        "v_mad_u64_u32 v[100:101], %[dm], %[s0], %[n0], 0\n\t"
+        "v_mul_lo_u32 v125, %[s3], %[m0]\n\t"
+        "v_mul_lo_u32 v97, %[s3], %[n0]\n\t"
+        "v_mul_lo_u32 v122, %[s0], %[m3]\n\t"
+        "v_mul_lo_u32 v94, %[s0], %[n3]\n\t"
+        "v_mov_b32 v120, v113\n\t"
+        "v_mov_b32 v108, v101\n\t"
+        "v_mad_u64_u32 v[114:115], %[dm], %[s0], %[m1], v[120:121]\n\t"
+        "v_mad_u64_u32 v[102:103], %[dm], %[s0], %[n1], v[108:109]\n\t"
+        "v_mul_lo_u32 v123, %[s1], %[m2]\n\t"
+        "v_mul_lo_u32 v95, %[s1], %[n2]\n\t"
+        "v_mul_lo_u32 v124, %[s2], %[m1]\n\t"
+        "v_mul_lo_u32 v96, %[s2], %[n1]\n\t"
+        "v_mov_b32 v120, v114\n\t"
+        "v_mov_b32 v108, v102\n\t"
+        "v_mad_u64_u32 v[116:117], %[dm], %[s1], %[m0], v[120:121]\n\t"
+        "v_mad_u64_u32 v[104:105], %[dm], %[s1], %[n0], v[108:109]\n\t"
+        "v_mov_b32 v120, v115\n\t"
+        "v_mov_b32 v108, v103\n\t"
+        "v_mad_u64_u32 v[118:119], %[dm], %[s0], %[m2], v[120:121]\n\t"
+        "v_mad_u64_u32 v[106:107], %[dm], %[s0], %[n2], v[108:109]\n\t"
+        "v_add3_u32 v122, v122, v123, v124\n\t"
+        "v_add3_u32 v94, v94, v95, v96\n\t"
+        "v_mad_u64_u32 v[118:119], %[dm], %[s1], %[m1], v[118:119]\n\t"
+        "v_mad_u64_u32 v[106:107], %[dm], %[s1], %[n1], v[106:107]\n\t"
+        "v_mov_b32 v120, v117\n\t"
+        "v_mov_b32 v108, v105\n\t"
+        "v_mad_u64_u32 v[118:119], %[dm], %[s2], %[m0], v[118:119]\n\t"
+        "v_mad_u64_u32 v[106:107], %[dm], %[s2], %[n0], v[106:107]\n\t"
+        "v_add_u32 v122, v122, v125\n\t"
+        "v_add_u32 v94, v94, v97\n\t"
+        "v_lshl_add_u64 v[118:119], v[118:119], 0, v[120:121]\n\t"
+        "v_lshl_add_u64 v[106:107], v[106:107], 0, v[108:109]\n\t"
+        "v_add_co_u32 v90, vcc, v112, %[i0]\n\t"              /* chain A's state: s_{n+1}, only its output is needed */
+        "v_addc_co_u32 v91, vcc, v116, %[i1], vcc\n\t"
+        "v_add_u32 v122, v122, v119\n\t"
+        "v_addc_co_u32 v92, vcc, v118, %[i2], vcc\n\t"
+        "v_addc_co_u32 v93, vcc, v122, %[i3], vcc\n\t"
+        "v_add_co_u32 %[s0], vcc, v100, %[j0]\n\t"            /* chain B's is the new state: every read of s is behind us */
+        "v_addc_co_u32 %[s1], vcc, v104, %[j1], vcc\n\t"
+        "v_add_u32 v94, v94, v107\n\t"
+        "v_addc_co_u32 %[s2], vcc, v106, %[j2], vcc\n\t"
+        "v_addc_co_u32 %[s3], vcc, v94, %[j3], vcc\n\t"
+        "v_xor_b32 v126, v90, v92\n\t"
+        "v_xor_b32 v98, %[s0], %[s2]\n\t"
+        "v_xor_b32 v127, v91, v93\n\t"
+        "v_xor_b32 v99, %[s1], %[s3]\n\t"
+        "v_lshrrev_b32 v123, 26, v93\n\t"
+        "v_lshrrev_b32 v95, 26, %[s3]\n\t"
+        "v_cmp_gt_i32 vcc, 0, v93\n\t"
+        "v_cmp_gt_i32_e64 %[cm], 0, %[s3]\n\t"
+        "v_cndmask_b32 v124, v126, v127, vcc\n\t"
+        "v_cndmask_b32_e64 v96, v98, v99, %[cm]\n\t"
+        "v_cndmask_b32 v125, v127, v126, vcc\n\t"
+        "v_cndmask_b32_e64 v97, v99, v98, %[cm]\n\t"
+        "v_and_or_b32 v122, %[w10], %[mask], %[lane]\n\t"
+        "v_add_u32 %[w10], 0x400, %[w10]\n\t"
+        "v_alignbit_b32 v124, v124, v125, v123\n\t"
+        "v_alignbit_b32 v96, v96, v97, v95\n\t"
+        "v_and_or_b32 v94, %[w10], %[mask], %[lane]\n\t"
+        "v_add_u32 %[left], -1, %[left]\n\t"
+        "v_add_u32 %[w10], 0x400, %[w10]\n\t"
+        "ds_write_b32 v122, v124\n\t"
+        "v_cmp_ne_u32_e64 %[cm], 0, %[left]\n\t"
+        "ds_write_b32 v94, v96\n\t"
+        "s_and_b64 exec, exec, %[cm]\n\t"
+        "s_cbranch_execnz 1b\n"
+        "3:\n\t"
+        "s_mov_b64 exec, %[sv]"
+        : [s0] "+v"(s0), [s1] "+v"(s1), [s2] "+v"(s2), [s3] "+v"(s3), [w10] "+v"(w10), [left] "+v"(left), [sv] "=&s"(sv),
+          [cm] "=&s"(cm), [dm] "=&s"(dm)
+        : [i0] "v"(i0), [i1] "v"(i1), [i2] "v"(i2), [i3] "v"(i3), [j0] "v"(j0), [j1] "v"(j1), [j2] "v"(j2), [j3] "v"(j3),
+          [m0] "s"(m0), [m1] "s"(m1), [m2] "s"(m2), [m3] "s"(m3), [n0] "s"(n0), [n1] "s"(n1), [n2] "s"(n2), [n3] "s"(n3),
+          [mask] "s"(kMask), [lane] "v"(lane_addr)
+        : "vcc", "memory", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103",
+          "v104", "v105", "v106", "v107", "v108", "v109", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120",
+          "v121", "v122", "v123", "v124", "v125", "v126", "v127");
+    g.s_lo = (uint64_t)s0 | ((uint64_t)s1 << 32);
+    g.s_hi = (uint64_t)s2 | ((uint64_t)s3 << 32);
+    w += 2u * pairs;
+}
+
 // The same hand-placed loop for a lane that advances its own generator (one-lane-per-env kernels: k_step,
 // k_rollout).  Per draw: the 128-bit LCG step on 32-bit limbs (6 v_mad_u64_u32 + 4 v_mul_lo_u32, the {carry, 0}
 // addends through one scratch pair), the upper half of the XSL-RR output, and the decision of draw_units_ring;

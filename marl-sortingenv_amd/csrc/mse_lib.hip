@@ -794,6 +794,8 @@ __global__ __launch_bounds__(kRingThreads) void k_rollout_ring(Params P, uint4 *
             g.i_hi = (uint64_t)b.z | ((uint64_t)b.w << 32);
         }
         const uint32_t ring_lane_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)(lring + el);
+        uint64_t c2_lo, c2_hi; // (M + 1) inc: the increment of the double step s_{n+2} = M^2 s_n + (M + 1) inc
+        mul128(0x4385DF649FCCF646ull, 0x2360ED051FC65DA4ull, g.i_lo, g.i_hi, c2_lo, c2_hi);
         // Production is demand-driven.  After B_s the lane knows r_s (outputs consumed through step s); the
         // outputs of step s+1 (< r_s + worst) are in place already, those of step s+2 (< r_s + 2 worst) must be
         // before B_{s+1}: that is `need`.  `cap` is how far a lane may run ahead: the ring's 64 slots, but
@@ -829,7 +831,11 @@ __global__ __launch_bounds__(kRingThreads) void k_rollout_ring(Params P, uint4 *
 #ifdef MSE_ABL_NORNG // (ablation timing builds only: the ring holds garbage, the stream is not advanced)
             w += M < room ? M : room;
 #else
-            ring_produce(g, w, M < room ? M : room, ring_lane_addr);
+            {
+                const uint32_t count = M < room ? M : room;
+                ring_produce_pairs(g, w, count >> 1, ring_lane_addr, c2_lo, c2_hi); // two outputs per iteration ...
+                ring_produce(g, w, count & 1u, ring_lane_addr);                     // ... and the odd one
+            }
 #endif
             MSE_TLB(tl, 0);
             lds_barrier_all(); // s == -1: B_init (first outputs are in place); else B_s

@@ -699,6 +699,93 @@ struct RingLayout {
     static constexpr int table_offset = pos_offset + pos_bytes; // multiple of 16
 };
 
+// The RNG role of k_rollout_ring: one lane per env runs that env's
+// PCG64 stream ahead into the LDS ring.  Every wave of the workgroup meets at one barrier per step (lds_barrier_all): the
+// first one (B_init) publishes the ring's priming, B_s the outputs step s + 1 may consume; lpos[el] is the consumer's
+// count after step s.  two_halves: the consumer side's idle lanes have produced [worst, 2 worst) before B_init.
+__device__ __forceinline__ void rng_server_role(const Params &P, uint4 *__restrict__ planes, const Tables &tb, long long i,
+                                                bool live, int k_steps, uint32_t *lring, uint32_t *lpos, int el, bool two_halves)
+{
+    Pcg g;
+    {
+        const uint4 a = planes[PL_RNG_STATE * P.n_pad + i], b = planes[PL_RNG_INC * P.n_pad + i];
+        g.s_lo = (uint64_t)a.x | ((uint64_t)a.y << 32);
+        g.s_hi = (uint64_t)a.z | ((uint64_t)a.w << 32);
+        g.i_lo = (uint64_t)b.x | ((uint64_t)b.y << 32);
+        g.i_hi = (uint64_t)b.z | ((uint64_t)b.w << 32);
+    }
+    const uint32_t ring_lane_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)(lring + el);
+    uint64_t c2_lo, c2_hi; // (M + 1) inc: the increment of the double step s_{n+2} = M^2 s_n + (M + 1) inc
+    mul128(0x4385DF649FCCF646ull, 0x2360ED051FC65DA4ull, g.i_lo, g.i_hi, c2_lo, c2_hi);
+    // Production is demand-driven.  After B_s the lane knows r_s (outputs consumed through step s); the
+    // outputs of step s+1 (< r_s + worst) are in place already, those of step s+2 (< r_s + 2 worst) must be
+    // before B_{s+1}: that is `need`.  `cap` is how far a lane may run ahead: the ring's 64 slots, but
+    // never past what the remaining steps of this launch can consume.  The wave keeps going while ANY lane
+    // is below its need and every lane below its cap produces along, so a lane that drew a lot last step
+    // does not cost the wave max(draws) iterations every step: the run-ahead slack (64 - 2 worst) smooths
+    // the per-step spread (6 or 19 draws with the default config) towards the long-run mean.
+    const uint32_t worst = (uint32_t)P.ring_worst;
+    uint32_t w = 0, need = worst, cap = need; // step 0's outputs, in place before B_init
+    // The ring is primed in two halves: this lane produces outputs [0, worst) and, in parallel on the same SIMD,
+    // the env's OBSERVER lane - idle until the first snapshot - produces [worst, 2 worst) from a state it reaches
+    // by one table-driven jump.  At B_init the ring then holds what B_0 asks for (r_{-1} + 2 worst), so step 0
+    // does not wait for a second round of production; this lane jumps over the observer's half after B_init.
+    // The deeper start also smooths the wave's per-step production for the rest of the launch.  Same-box T(K): the
+    // observer's half ends ~0.7 us after this lane's, paid back from K = 16 on (K = 2: +0.75 us, 16-20: equal,
+    // 32: -0.8 %, 64: -1.2 %), hence only for launches of kRingTwoHalvesFrom steps or more.
+#ifdef MSE_TIMELINE
+    Timeline tl;
+    tl.start();
+#endif
+    for (int s = -1; s < k_steps; ++s) {
+        // M = the largest shortfall in the wave (a 6-bit maximum found bit by bit with ballots, in SGPRs);
+        // every lane then produces min(M, its room): a plain per-lane trip count for the loop below
+        const uint32_t deficit = need > w ? need - w : 0u; // <= 2 worst <= 62
+        uint32_t M = 0;
+#pragma unroll
+        for (int bit = 5; bit >= 0; --bit) {
+            const uint32_t cand = M | (1u << bit);
+            if (__builtin_amdgcn_ballot_w64(deficit >= cand) != 0ull) M = cand;
+        }
+        const uint32_t room = cap > w ? cap - w : 0u;
+#ifdef MSE_ABL_NORNG // (ablation timing builds only: the ring holds garbage, the stream is not advanced)
+        w += M < room ? M : room;
+#else
+        {
+            const uint32_t count = M < room ? M : room;
+            ring_produce_pairs(g, w, count >> 1, ring_lane_addr, c2_lo, c2_hi); // two outputs per iteration ...
+            ring_produce(g, w, count & 1u, ring_lane_addr);                     // ... and the odd one
+        }
+#endif
+        MSE_TLB(tl, 0);
+        lds_barrier_all(); // s == -1: B_init (first outputs are in place); else B_s
+        MSE_TLB(tl, 1);
+        if (s < 0 && two_halves) {
+            pcg_affine(g, P.ring_fwd[0], P.ring_fwd[1], P.ring_fwd[2], P.ring_fwd[3]); // + worst
+            w += worst;
+        }
+        const uint32_t steps_left = (uint32_t)(k_steps - 1 - s); // steps s+1 .. K-1
+        const uint32_t r = lpos[el];                             // 0 at B_init
+        const uint32_t ahead = worst * steps_left;
+        need = r + worst * (steps_left < 2u ? steps_left : 2u);
+        cap = r + (ahead < (uint32_t)kRingDepth ? ahead : (uint32_t)kRingDepth);
+    }
+    // hand the stream back: this lane stands d <= worst outputs past what the env consumed (nothing is
+    // produced after the last barrier, and before it at most `worst` per remaining step)
+    {
+        uint32_t d = w - lpos[el]; // <= 64, the ring's depth
+        if (__builtin_expect(d > 32u, 0)) { // only after steps that drew nothing (an episode's first two)
+            pcg_step_back(g, 32u, tb.back);
+            d -= 32u;
+        }
+        pcg_step_back(g, d, tb.back);
+        if (live) planes[PL_RNG_STATE * P.n_pad + i] = pack_u64x2(g.s_lo, g.s_hi);
+    }
+#ifdef MSE_TIMELINE
+    tl.flush(2);
+#endif
+}
+
 constexpr int kRingTwoHalvesFrom = 16; // launches this long prime the ring in two halves (RNG + observer lanes)
 
 #ifdef MSE_CLOCK_PROBE
@@ -784,86 +871,7 @@ __global__ __launch_bounds__(kRingThreads) void k_rollout_ring(Params P, uint4 *
     MSE_TL(edge, 0); // state loads and the table image -> LDS
 
     if (role == 2) {
-        // ------------------------------------------------------------------ RNG waves
-        Pcg g;
-        {
-            const uint4 a = planes[PL_RNG_STATE * P.n_pad + i], b = planes[PL_RNG_INC * P.n_pad + i];
-            g.s_lo = (uint64_t)a.x | ((uint64_t)a.y << 32);
-            g.s_hi = (uint64_t)a.z | ((uint64_t)a.w << 32);
-            g.i_lo = (uint64_t)b.x | ((uint64_t)b.y << 32);
-            g.i_hi = (uint64_t)b.z | ((uint64_t)b.w << 32);
-        }
-        const uint32_t ring_lane_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)(lring + el);
-        uint64_t c2_lo, c2_hi; // (M + 1) inc: the increment of the double step s_{n+2} = M^2 s_n + (M + 1) inc
-        mul128(0x4385DF649FCCF646ull, 0x2360ED051FC65DA4ull, g.i_lo, g.i_hi, c2_lo, c2_hi);
-        // Production is demand-driven.  After B_s the lane knows r_s (outputs consumed through step s); the
-        // outputs of step s+1 (< r_s + worst) are in place already, those of step s+2 (< r_s + 2 worst) must be
-        // before B_{s+1}: that is `need`.  `cap` is how far a lane may run ahead: the ring's 64 slots, but
-        // never past what the remaining steps of this launch can consume.  The wave keeps going while ANY lane
-        // is below its need and every lane below its cap produces along, so a lane that drew a lot last step
-        // does not cost the wave max(draws) iterations every step: the run-ahead slack (64 - 2 worst) smooths
-        // the per-step spread (6 or 19 draws with the default config) towards the long-run mean.
-        const uint32_t worst = (uint32_t)P.ring_worst;
-        uint32_t w = 0, need = worst, cap = need; // step 0's outputs, in place before B_init
-        // The ring is primed in two halves: this lane produces outputs [0, worst) and, in parallel on the same SIMD,
-        // the env's OBSERVER lane - idle until the first snapshot - produces [worst, 2 worst) from a state it reaches
-        // by one table-driven jump.  At B_init the ring then holds what B_0 asks for (r_{-1} + 2 worst), so step 0
-        // does not wait for a second round of production; this lane jumps over the observer's half after B_init.
-        // The deeper start also smooths the wave's per-step production for the rest of the launch.  Same-box T(K): the
-        // observer's half ends ~0.7 us after this lane's, paid back from K = 16 on (K = 2: +0.75 us, 16-20: equal,
-        // 32: -0.8 %, 64: -1.2 %), hence only for launches of kRingTwoHalvesFrom steps or more.
-        const bool two_halves = k_steps >= kRingTwoHalvesFrom;
-#ifdef MSE_TIMELINE
-        Timeline tl;
-        tl.start();
-#endif
-        for (int s = -1; s < k_steps; ++s) {
-            // M = the largest shortfall in the wave (a 6-bit maximum found bit by bit with ballots, in SGPRs);
-            // every lane then produces min(M, its room): a plain per-lane trip count for the loop below
-            const uint32_t deficit = need > w ? need - w : 0u; // <= 2 worst <= 62
-            uint32_t M = 0;
-#pragma unroll
-            for (int bit = 5; bit >= 0; --bit) {
-                const uint32_t cand = M | (1u << bit);
-                if (__builtin_amdgcn_ballot_w64(deficit >= cand) != 0ull) M = cand;
-            }
-            const uint32_t room = cap > w ? cap - w : 0u;
-#ifdef MSE_ABL_NORNG // (ablation timing builds only: the ring holds garbage, the stream is not advanced)
-            w += M < room ? M : room;
-#else
-            {
-                const uint32_t count = M < room ? M : room;
-                ring_produce_pairs(g, w, count >> 1, ring_lane_addr, c2_lo, c2_hi); // two outputs per iteration ...
-                ring_produce(g, w, count & 1u, ring_lane_addr);                     // ... and the odd one
-            }
-#endif
-            MSE_TLB(tl, 0);
-            lds_barrier_all(); // s == -1: B_init (first outputs are in place); else B_s
-            MSE_TLB(tl, 1);
-            if (s < 0 && two_halves) {
-                pcg_affine(g, P.ring_fwd[0], P.ring_fwd[1], P.ring_fwd[2], P.ring_fwd[3]); // + worst
-                w += worst;
-            }
-            const uint32_t steps_left = (uint32_t)(k_steps - 1 - s); // steps s+1 .. K-1
-            const uint32_t r = lpos[el];                             // 0 at B_init
-            const uint32_t ahead = worst * steps_left;
-            need = r + worst * (steps_left < 2u ? steps_left : 2u);
-            cap = r + (ahead < (uint32_t)kRingDepth ? ahead : (uint32_t)kRingDepth);
-        }
-        // hand the stream back: this lane stands d <= worst outputs past what the env consumed (nothing is
-        // produced after the last barrier, and before it at most `worst` per remaining step)
-        {
-            uint32_t d = w - lpos[el]; // <= 64, the ring's depth
-            if (__builtin_expect(d > 32u, 0)) { // only after steps that drew nothing (an episode's first two)
-                pcg_step_back(g, 32u, tb.back);
-                d -= 32u;
-            }
-            pcg_step_back(g, d, tb.back);
-            if (live) planes[PL_RNG_STATE * P.n_pad + i] = pack_u64x2(g.s_lo, g.s_hi);
-        }
-#ifdef MSE_TIMELINE
-        tl.flush(2);
-#endif
+        rng_server_role(P, planes, tb, i, live, k_steps, lring, lpos, el, k_steps >= kRingTwoHalvesFrom);
     } else if (role == 0) {
         // ------------------------------------------------------------------ dynamics waves
         // the critical path of the pipeline: let their instructions win the SIMD's issue arbitration over the

@@ -219,7 +219,10 @@ def test_f16x3_form_tracks_the_exact_f32_form():
 @pytest.mark.parametrize("precision", ["f16x3", "f32"])
 @pytest.mark.parametrize("kind,noise,n,K", [("mono", 0.0, 5000, 24), ("mono", 0.05, 777, 23), ("press", 0.05, 1030, 21),
                                             ("sort", 0.0, 600, 25), ("mono", 0.0, 70300, 6), ("mono", 0.05, 1, 14),
-                                            ("press", 0.0, 33, 14)])
+                                            ("press", 0.0, 33, 14),
+                                            # whole workgroups, and the 65 536 envs of the headline batch
+                                            ("mono", 0.0, 1024, 24), ("mono", 0.05, 512, 23), ("press", 0.05, 256, 21),
+                                            ("sort", 0.0, 768, 25), ("mono", 0.0, 65536, 7)])
 def test_fused_policy_rollout_equals_two_launch_collector(kind, noise, n, K, precision):
     """mse_rollout_policy (policy forward inside the rollout kernel, one launch per rollout) fills the same
     MaskableRolloutBuffer-shaped tensors, bit for bit, as alternating mse_policy_forward and mse_step; the env state

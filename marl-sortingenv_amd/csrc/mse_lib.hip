@@ -257,13 +257,18 @@ __device__ __forceinline__ void stage_and_store_halves(uint8_t *lds_base, const 
 
 // LDS of the one-lane rollout kernel: [half observation tiles, 32 rows per wave][bale ledger, 12-byte cells][tables up
 // to the jump tables, which only the three-role kernel reads]: 38 KB for Env_3, four workgroups per CU
-template <int KIND>
+template <int KIND, bool NOISE = false>
 struct RolloutLayout {
     static constexpr int D = Dims<KIND>::D;
     static constexpr int tile_bytes = (kBlock / 2 * D * 4 + 15) / 16 * 16;
     static constexpr int bale_offset = tile_bytes;
     static constexpr int bale_bytes = 5 * 3 * kBlock * 4; // BaleRefCompact: 12 bytes per cell
-    static constexpr int table_offset = bale_offset + bale_bytes;
+    // noise > 0: the increment of rng_noise (constant for the launch) waits here between two update_accuracy calls
+    // instead of in four registers: at the 168-register cap of three workgroups per CU the Env_3 noise instantiation
+    // kept two dwords of the step loop in scratch memory (20.0 G against 23.4 without noise at 262 144 envs)
+    static constexpr int noise_offset = bale_offset + bale_bytes;
+    static constexpr int noise_bytes = NOISE ? kBlock * 16 : 0;
+    static constexpr int table_offset = noise_offset + noise_bytes;
 };
 
 // auto-reset of a finished episode inside the step (reset(seed=None) semantics: streams continue)
@@ -423,8 +428,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
 {
     constexpr int D = Dims<KIND>::D, A = Dims<KIND>::A;
     uint8_t *lds = reinterpret_cast<uint8_t *>(mse_dyn_lds);
-    uint32_t *ltab = reinterpret_cast<uint32_t *>(lds + RolloutLayout<KIND>::table_offset);
-    uint32_t *lbale = reinterpret_cast<uint32_t *>(lds + RolloutLayout<KIND>::bale_offset);
+    uint32_t *ltab = reinterpret_cast<uint32_t *>(lds + RolloutLayout<KIND, NOISE>::table_offset);
+    uint32_t *lbale = reinterpret_cast<uint32_t *>(lds + RolloutLayout<KIND, NOISE>::bale_offset);
+    uint4 *lnoise = reinterpret_cast<uint4 *>(lds + RolloutLayout<KIND, NOISE>::noise_offset);
     const int tid = threadIdx.x;
     const long long row0 = (long long)blockIdx.x * kBlock;
     const long long i = row0 + tid; // i < n_pad always: the planes are padded to whole workgroups
@@ -452,6 +458,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
     __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
     uint32_t cur_mask = live ? action_mask_bits<KIND>(e, P) : 1u;
     const uint32_t pkey = mse_policy_key(policy_seed, (uint64_t)(P.index_offset + i));
+    if (NOISE && live) lnoise[tid] = pack_u64x2(e.noise.i_lo, e.noise.i_hi);
 
     for (int s = 0; s < k_steps; ++s) {
         float o[D]; // per step: nothing of the observation lives across the loop's back edge
@@ -460,6 +467,11 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
         uint32_t mbits = 0;
         const long long srow = (long long)s * P.n + row0;
         if (live) {
+            if (NOISE) { // the parked increment comes back for this step's update_accuracy (RolloutLayout::noise_offset)
+                const uint4 q = lnoise[tid];
+                e.noise.i_lo = (uint64_t)q.x | ((uint64_t)q.y << 32);
+                e.noise.i_hi = (uint64_t)q.z | ((uint64_t)q.w << 32);
+            }
             int a = policy_action<KIND, GEN>(e, cur_mask, tb, flags, pkey, policy_t0 + (uint64_t)s);
             int k[4];
             StepResult r = env_step<KIND, NOISE, LITERAL, false, GEN, BaleRefCompact>(e, P, tb, a, sm, flags, bales, k, o);
@@ -1896,7 +1908,8 @@ static size_t lds_bytes_step(const mse_env *h)
 template <int KIND>
 static size_t lds_bytes_rollout(const mse_env *h)
 {
-    return (size_t)RolloutLayout<KIND>::table_offset + (size_t)(h->P.gen_mode ? h->P.table_words : h->P.off_jump) * 4u;
+    return (size_t)(h->noise_on ? RolloutLayout<KIND, true>::table_offset : RolloutLayout<KIND, false>::table_offset) +
+           (size_t)(h->P.gen_mode ? h->P.table_words : h->P.off_jump) * 4u;
 }
 
 static inline dim3 grid_of(const mse_env *h) { return dim3((unsigned)(h->P.n_pad / kBlock)); }

@@ -938,9 +938,11 @@ __device__ __forceinline__ void draw_units_ring(RngRing &rng, uint32_t &C, int &
 }
 
 // The RNG lane's production loop (k_rollout_ring): `count` PCG64 steps, the upper 32 output bits of each stored
-// at LDS row (w & 63) of the lane's ring column (lane_addr, 64 KiB-aligned ring).  The same 21-instruction LCG step
-// and 7-instruction output as draw_units_local, an address in two instructions and three of loop control: 34 per
-// output against 38 + 7 scalar from the structured C++ loop.  Products and carries live in v[112:121].
+// at LDS row (w & 63) of the lane's ring column (lane_addr, 64 KiB-aligned ring).  The LCG step takes 19 instructions
+// (round 2: 21): limb 1 is the low word of Y = s1 m0 + (s0 m1 + hi(s0 m0)) as ONE 64-bit multiply-add whose carry-out
+// (the 65th bit, an SGPR mask) joins limb 3 in the add that was there anyway - the upper word of Y then carries into
+// limbs 2..3 by one zero-extending move instead of two moves and a 64-bit add.  With the 7-instruction output, an
+// address in two and three of loop control: 32 per output.  Products and carries live in v[112:121].
 __device__ __forceinline__ void ring_produce(Pcg &g, uint32_t &w, uint32_t count, uint32_t lane_addr)
 {
     uint32_t s0 = (uint32_t)g.s_lo, s1 = (uint32_t)(g.s_lo >> 32), s2 = (uint32_t)g.s_hi, s3 = (uint32_t)(g.s_hi >> 32);
@@ -948,7 +950,7 @@ __device__ __forceinline__ void ring_produce(Pcg &g, uint32_t &w, uint32_t count
     const uint32_t m0 = 0x9FCCF645u, m1 = 0x4385DF64u, m2 = 0x1FC65DA4u, m3 = 0x2360ED05u, kMask = 0xFC00u;
     uint32_t w10 = w << 10, left = count;
     uint32_t t0, t1, t2, t3, x, y;
-    uint64_t sv, cm, dm;
+    uint64_t sv, cm, dm, cy;
     asm volatile(
         "s_mov_b64 %[sv], exec\n\t"
         "v_cmp_ne_u32 vcc, 0, %[left]\n\t"
@@ -963,19 +965,16 @@ __device__ __forceinline__ void ring_produce(Pcg &g, uint32_t &w, uint32_t count
         "v_mad_u64_u32 v[114:115], %[dm], %[s0], %[m1], v[120:121]\n\t"
         "v_mul_lo_u32 %[t1], %[s1], %[m2]\n\t"
         "v_mul_lo_u32 %[t2], %[s2], %[m1]\n\t"
-        "v_mov_b32 v120, v114\n\t"
-        "v_mad_u64_u32 v[116:117], %[dm], %[s1], %[m0], v[120:121]\n\t"
-        "v_mov_b32 v120, v115\n\t"
-        "v_mad_u64_u32 v[118:119], %[dm], %[s0], %[m2], v[120:121]\n\t"
+        "v_mad_u64_u32 v[116:117], %[cy], %[s1], %[m0], v[114:115]\n\t"
         "v_add3_u32 %[t0], %[t0], %[t1], %[t2]\n\t"
-        "v_mad_u64_u32 v[118:119], %[dm], %[s1], %[m1], v[118:119]\n\t"
         "v_mov_b32 v120, v117\n\t"
-        "v_mad_u64_u32 v[118:119], %[dm], %[s2], %[m0], v[118:119]\n\t"
+        "v_mad_u64_u32 v[118:119], %[dm], %[s0], %[m2], v[120:121]\n\t"
         "v_add_u32 %[t0], %[t0], %[t3]\n\t"
-        "v_lshl_add_u64 v[118:119], v[118:119], 0, v[120:121]\n\t"
+        "v_mad_u64_u32 v[118:119], %[dm], %[s1], %[m1], v[118:119]\n\t"
+        "v_mad_u64_u32 v[118:119], %[dm], %[s2], %[m0], v[118:119]\n\t"
+        "v_addc_co_u32_e64 %[t0], %[dm], v119, %[t0], %[cy]\n\t"
         "v_add_co_u32 %[s0], vcc, v112, %[i0]\n\t"
         "v_addc_co_u32 %[s1], vcc, v116, %[i1], vcc\n\t"
-        "v_add_u32 %[t0], %[t0], v119\n\t"
         "v_addc_co_u32 %[s2], vcc, v118, %[i2], vcc\n\t"
         "v_addc_co_u32 %[s3], vcc, %[t0], %[i3], vcc\n\t"
         "v_xor_b32 %[x], %[s0], %[s2]\n\t"
@@ -996,7 +995,7 @@ __device__ __forceinline__ void ring_produce(Pcg &g, uint32_t &w, uint32_t count
         "s_mov_b64 exec, %[sv]"
         : [s0] "+v"(s0), [s1] "+v"(s1), [s2] "+v"(s2), [s3] "+v"(s3), [w10] "+v"(w10), [left] "+v"(left), [t0] "=&v"(t0),
           [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [x] "=&v"(x), [y] "=&v"(y), [sv] "=&s"(sv), [cm] "=&s"(cm),
-          [dm] "=&s"(dm)
+          [dm] "=&s"(dm), [cy] "=&s"(cy)
         : [i0] "v"(i0), [i1] "v"(i1), [i2] "v"(i2), [i3] "v"(i3), [m0] "s"(m0), [m1] "s"(m1), [m2] "s"(m2), [m3] "s"(m3),
           [mask] "s"(kMask), [lane] "v"(lane_addr)
         : "vcc", "memory", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121");
@@ -1021,7 +1020,7 @@ __device__ __forceinline__ void ring_produce_pairs(Pcg &g, uint32_t &w, uint32_t
     const uint32_t m0 = 0x9FCCF645u, m1 = 0x4385DF64u, m2 = 0x1FC65DA4u, m3 = 0x2360ED05u, kMask = 0xFC00u;
     const uint32_t n0 = 0x20E0AE99u, n1 = 0x529ED9EBu, n2 = 0xDF69743Cu, n3 = 0x17BCE35Bu; // M^2 mod 2^128
     uint32_t w10 = w << 10, left = pairs;
-    uint64_t sv, cm, dm;
+    uint64_t sv, cm, dm, cy, cy2;
     asm volatile(
         "s_mov_b64 %[sv], exec\n\t"
         "v_cmp_ne_u32 vcc, 0, %[left]\n\t"
@@ -1044,34 +1043,28 @@ __device__ __forceinline__ void ring_produce_pairs(Pcg &g, uint32_t &w, uint32_t
         "v_mul_lo_u32 v95, %[s1], %[n2]\n\t"
         "v_mul_lo_u32 v124, %[s2], %[m1]\n\t"
         "v_mul_lo_u32 v96, %[s2], %[n1]\n\t"
-        "v_mov_b32 v120, v114\n\t"
-        "v_mov_b32 v108, v102\n\t"
-        "v_mad_u64_u32 v[116:117], %[dm], %[s1], %[m0], v[120:121]\n\t"
-        "v_mad_u64_u32 v[104:105], %[dm], %[s1], %[n0], v[108:109]\n\t"
-        "v_mov_b32 v120, v115\n\t"
-        "v_mov_b32 v108, v103\n\t"
-        "v_mad_u64_u32 v[118:119], %[dm], %[s0], %[m2], v[120:121]\n\t"
-        "v_mad_u64_u32 v[106:107], %[dm], %[s0], %[n2], v[108:109]\n\t"
+        "v_mad_u64_u32 v[116:117], %[cy], %[s1], %[m0], v[114:115]\n\t"
+        "v_mad_u64_u32 v[104:105], %[cy2], %[s1], %[n0], v[102:103]\n\t"
         "v_add3_u32 v122, v122, v123, v124\n\t"
         "v_add3_u32 v94, v94, v95, v96\n\t"
-        "v_mad_u64_u32 v[118:119], %[dm], %[s1], %[m1], v[118:119]\n\t"
-        "v_mad_u64_u32 v[106:107], %[dm], %[s1], %[n1], v[106:107]\n\t"
         "v_mov_b32 v120, v117\n\t"
         "v_mov_b32 v108, v105\n\t"
-        "v_mad_u64_u32 v[118:119], %[dm], %[s2], %[m0], v[118:119]\n\t"
-        "v_mad_u64_u32 v[106:107], %[dm], %[s2], %[n0], v[106:107]\n\t"
+        "v_mad_u64_u32 v[118:119], %[dm], %[s0], %[m2], v[120:121]\n\t"
+        "v_mad_u64_u32 v[106:107], %[dm], %[s0], %[n2], v[108:109]\n\t"
         "v_add_u32 v122, v122, v125\n\t"
         "v_add_u32 v94, v94, v97\n\t"
-        "v_lshl_add_u64 v[118:119], v[118:119], 0, v[120:121]\n\t"
-        "v_lshl_add_u64 v[106:107], v[106:107], 0, v[108:109]\n\t"
-        "v_add_co_u32 v90, vcc, v112, %[i0]\n\t"              /* chain A's state: s_{n+1}, only its output is needed */
+        "v_mad_u64_u32 v[118:119], %[dm], %[s1], %[m1], v[118:119]\n\t"
+        "v_mad_u64_u32 v[106:107], %[dm], %[s1], %[n1], v[106:107]\n\t"
+        "v_mad_u64_u32 v[118:119], %[dm], %[s2], %[m0], v[118:119]\n\t"
+        "v_mad_u64_u32 v[106:107], %[dm], %[s2], %[n0], v[106:107]\n\t"
+        "v_addc_co_u32_e64 v122, %[dm], v119, v122, %[cy]\n\t"
+        "v_add_co_u32 v90, vcc, v112, %[i0]\n\t"
         "v_addc_co_u32 v91, vcc, v116, %[i1], vcc\n\t"
-        "v_add_u32 v122, v122, v119\n\t"
         "v_addc_co_u32 v92, vcc, v118, %[i2], vcc\n\t"
         "v_addc_co_u32 v93, vcc, v122, %[i3], vcc\n\t"
-        "v_add_co_u32 %[s0], vcc, v100, %[j0]\n\t"            /* chain B's is the new state: every read of s is behind us */
+        "v_addc_co_u32_e64 v94, %[dm], v107, v94, %[cy2]\n\t"
+        "v_add_co_u32 %[s0], vcc, v100, %[j0]\n\t"
         "v_addc_co_u32 %[s1], vcc, v104, %[j1], vcc\n\t"
-        "v_add_u32 v94, v94, v107\n\t"
         "v_addc_co_u32 %[s2], vcc, v106, %[j2], vcc\n\t"
         "v_addc_co_u32 %[s3], vcc, v94, %[j3], vcc\n\t"
         "v_xor_b32 v126, v90, v92\n\t"
@@ -1101,7 +1094,7 @@ __device__ __forceinline__ void ring_produce_pairs(Pcg &g, uint32_t &w, uint32_t
         "3:\n\t"
         "s_mov_b64 exec, %[sv]"
         : [s0] "+v"(s0), [s1] "+v"(s1), [s2] "+v"(s2), [s3] "+v"(s3), [w10] "+v"(w10), [left] "+v"(left), [sv] "=&s"(sv),
-          [cm] "=&s"(cm), [dm] "=&s"(dm)
+          [cm] "=&s"(cm), [dm] "=&s"(dm), [cy] "=&s"(cy), [cy2] "=&s"(cy2)
         : [i0] "v"(i0), [i1] "v"(i1), [i2] "v"(i2), [i3] "v"(i3), [j0] "v"(j0), [j1] "v"(j1), [j2] "v"(j2), [j3] "v"(j3),
           [m0] "s"(m0), [m1] "s"(m1), [m2] "s"(m2), [m3] "s"(m3), [n0] "s"(n0), [n1] "s"(n1), [n2] "s"(n2), [n3] "s"(n3),
           [mask] "s"(kMask), [lane] "v"(lane_addr)
@@ -1129,7 +1122,7 @@ __device__ __forceinline__ void draw_units_local(Pcg &g, uint32_t &C, int &rem, 
     const uint32_t m0 = 0x9FCCF645u, m1 = 0x4385DF64u, m2 = 0x1FC65DA4u, m3 = 0x2360ED05u;
     const uint32_t kSel = 0x0C000000u, kK = 0xFEFEFEFFu;
     uint32_t t0, t1, t2, t3, x, y;
-    uint64_t sv, cm, dm;
+    uint64_t sv, cm, dm, cy;
     asm volatile(
         "s_mov_b64 %[sv], exec\n\t"
         "v_cmp_ne_u32 vcc, 0, %[n]\n\t"
@@ -1145,19 +1138,16 @@ __device__ __forceinline__ void draw_units_local(Pcg &g, uint32_t &C, int &rem, 
         "v_mad_u64_u32 v[114:115], %[dm], %[s0], %[m1], v[120:121]\n\t"
         "v_mul_lo_u32 %[t1], %[s1], %[m2]\n\t"
         "v_mul_lo_u32 %[t2], %[s2], %[m1]\n\t"
-        "v_mov_b32 v120, v114\n\t"
-        "v_mad_u64_u32 v[116:117], %[dm], %[s1], %[m0], v[120:121]\n\t"
-        "v_mov_b32 v120, v115\n\t"
-        "v_mad_u64_u32 v[118:119], %[dm], %[s0], %[m2], v[120:121]\n\t"
+        "v_mad_u64_u32 v[116:117], %[cy], %[s1], %[m0], v[114:115]\n\t"
         "v_add3_u32 %[t0], %[t0], %[t1], %[t2]\n\t"
-        "v_mad_u64_u32 v[118:119], %[dm], %[s1], %[m1], v[118:119]\n\t"
         "v_mov_b32 v120, v117\n\t"
-        "v_mad_u64_u32 v[118:119], %[dm], %[s2], %[m0], v[118:119]\n\t"
+        "v_mad_u64_u32 v[118:119], %[dm], %[s0], %[m2], v[120:121]\n\t"
         "v_add_u32 %[t0], %[t0], %[t3]\n\t"
-        "v_lshl_add_u64 v[118:119], v[118:119], 0, v[120:121]\n\t"
+        "v_mad_u64_u32 v[118:119], %[dm], %[s1], %[m1], v[118:119]\n\t"
+        "v_mad_u64_u32 v[118:119], %[dm], %[s2], %[m0], v[118:119]\n\t"
+        "v_addc_co_u32_e64 %[t0], %[dm], v119, %[t0], %[cy]\n\t"
         "v_add_co_u32 %[s0], vcc, v112, %[i0]\n\t"
         "v_addc_co_u32 %[s1], vcc, v116, %[i1], vcc\n\t"
-        "v_add_u32 %[t0], %[t0], v119\n\t"
         "v_addc_co_u32 %[s2], vcc, v118, %[i2], vcc\n\t"
         "v_addc_co_u32 %[s3], vcc, %[t0], %[i3], vcc\n\t"
         /* upper 32 bits of rotr64(hi ^ lo, hi >> 58) */
@@ -1185,7 +1175,7 @@ __device__ __forceinline__ void draw_units_local(Pcg &g, uint32_t &C, int &rem, 
         "s_mov_b64 exec, %[sv]"
         : [s0] "+v"(s0), [s1] "+v"(s1), [s2] "+v"(s2), [s3] "+v"(s3), [cb] "+v"(Cb), [t] "+v"(T), [mn] "+v"(f_min),
           [mx] "+v"(f_max), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [x] "=&v"(x), [y] "=&v"(y),
-          [sv] "=&s"(sv), [cm] "=&s"(cm), [dm] "=&s"(dm)
+          [sv] "=&s"(sv), [cm] "=&s"(cm), [dm] "=&s"(dm), [cy] "=&s"(cy)
         : [i0] "v"(i0), [i1] "v"(i1), [i2] "v"(i2), [i3] "v"(i3), [m0] "s"(m0), [m1] "s"(m1), [m2] "s"(m2), [m3] "s"(m3),
           [sel] "s"(kSel), [k] "s"(kK), [tend] "v"(T_end), [n] "v"(n_draws)
         : "vcc", "memory", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123");

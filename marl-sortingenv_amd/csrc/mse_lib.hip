@@ -760,6 +760,14 @@ __device__ __forceinline__ void rng_server_role(const Params &P, uint4 *__restri
             if (__builtin_amdgcn_ballot_w64(deficit >= cand) != 0ull) M = cand;
         }
         const uint32_t room = cap > w ? cap - w : 0u;
+#ifdef MSE_TIMELINE
+        if (blockIdx.x == 0) { // diagnostic: the wave's trip count and what its lanes actually produce (sections 3, 4)
+            tl.acc[3] += M;
+            unsigned long long produced = 0;
+            for (int b = 0; b < 6; ++b) produced += ((unsigned long long)__builtin_popcountll(__builtin_amdgcn_ballot_w64((((M < room ? M : room) >> b) & 1u) != 0))) << b;
+            tl.acc[4] += produced;
+        }
+#endif
 #ifdef MSE_ABL_NORNG // (ablation timing builds only: the ring holds garbage, the stream is not advanced)
         w += M < room ? M : room;
 #else

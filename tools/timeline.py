@@ -42,7 +42,7 @@ waves = 4  # workgroup 0 only
 names = {
     0: ["policy", "flow+accuracy", "sort_material w/o loops", "press", "snapshot/levels", "mask+snap write", "barrier wait", "draw loops"],
     1: ["barrier wait", "snap read+observe", "stage+store", "", "", "", "", ""],
-    2: ["produce", "barrier wait", "", "", "", "", "", ""],
+    2: ["produce", "barrier wait", "", "trip count M (sum, not ticks)", "outputs produced by the wave's 64 lanes (sum, not ticks)", "", "", ""],
 }
 print(f"{kind} {n} envs noise {noise}: {ms * 1e3:.1f} us per launch of {K} steps = {ms * 1e3 / K:.2f} us/step (instrumented build)")
 ev = [out[24 + k] / (4 * launches) for k in range(6)]

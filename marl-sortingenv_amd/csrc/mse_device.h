@@ -810,9 +810,10 @@ struct RngCounted {
 //
 // How wide the margin must be.  r >> 11 = r_hi 2^21 + eps with r_hi = r >> 32 and eps < 2^21 the next 21 bits, so in
 // units of 2^-32:  u T = r_hi T + delta,  delta = eps T / 2^21 in [0, T), T <= 127:  floor(u T) = v unless
-// f + delta >= 2^32, which needs f >= 2^32 - 127.  The fp64 cdf is within 6 x 2^-53 of c_k / T (one division, up to
-// three additions, one division by cdf[-1] <= 1), i.e. within 2^-11.4 of these units after the scaling by T: it can only
-// disagree with the exact comparison when f + delta < 2^-11 (so f = 0) or f + delta > 2^32 - 2^-11 (so f >= 2^32 - 128).
+// f + delta >= 2^32, which needs f >= 2^32 - 127.  The fp64 cdf is within 2^-49 of c_k / T (four divisions l_k / T, up to
+// three additions, the division by cdf[-1]: a dozen roundings of values <= 1, each <= 2^-53), i.e. within 2^-10 of these
+// units after the scaling by T < 2^7: it can only disagree with the exact comparison when f + delta < 2^-10 (so f = 0) or
+// f + delta > 2^32 - 2^-10 (so f >= 2^32 - 128).
 // A draw is "near a tie" when f + MSE_TIE_HI < MSE_TIE_WINDOW (32-bit wrap-around): f < MSE_TIE_WINDOW - MSE_TIE_HI
 // (= 2 as shipped: f = 0 with a margin of one) or f >= 2^32 - MSE_TIE_HI (= 160: the 128 with a margin of 32), once in
 // 2.6 x 10^7 draws.  Round 2 shipped 16 / 512 (once in 8 x 10^6): at 65 536 envs a 20-step launch met ~2 such draws, and

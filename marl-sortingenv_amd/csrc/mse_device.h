@@ -865,17 +865,16 @@ __device__ __forceinline__ void draw_units(RNG &rng, uint32_t &C, int &rem)
 //   * D = (V | 0x808080) - C is carried with the bias folded in (Cb = C - 0x808080); the broadcast of v is a
 //     byte permute;
 //   * two ring outputs are in flight in two fixed registers (the body is unrolled twice; lanes that make an
-//     odd number of draws swap the pair on the way out), prefetched with a two-instruction address;
+//     odd number of draws swap the pair on the way out), prefetched from an address that one 16-bit add advances;
 //   * the near-tie test is only *recorded* (min and max of the fraction view f, folded in once per two draws):
 //     sort_material looks at them once per step and, about once in 10^6 steps, redoes the step literally.
 // On entry and exit rng.nxt / rng.nxt2 hold outputs #pos and #pos+1 (read after the step's barrier).
 // The two products live in v[124:127]: inline asm cannot name the halves of a 64-bit operand.
 #define MSE_RING_DRAW(PIN_HI, POUT, OUSE, OLOAD, EXTRA)        \
     "v_perm_b32 %[x], 0, " PIN_HI ", %[sel]\n\t"              \
-    "v_add_u32 %[p10], 0x400, %[p10]\n\t"                     \
+    "v_add_u16 %[a], 0x400, %[a]\n\t"                         \
     "v_add_u32 %[t], -1, %[t]\n\t"                            \
     "v_sub_u32 %[x], %[x], %[cb]\n\t"                         \
-    "v_and_or_b32 %[a], %[p10], %[mask], %[lane]\n\t"         \
     "v_cmp_ne_u32_e64 %[cm], %[t], %[tend]\n\t"               \
     "v_lshrrev_b32 %[x], 7, %[x]\n\t"                         \
     "ds_read_b32 %[" OLOAD "], %[a]\n\t"                      \
@@ -895,17 +894,20 @@ __device__ __forceinline__ void draw_units_ring(RngRing &rng, uint32_t &C, int &
     const uint32_t n_draws = (uint32_t)rem;  // rem <= T: a station's own false units are in the pool
     const uint32_t T_end = T - n_draws;
     uint32_t Cb = C - 0x00808080u;
-    uint32_t x, a;
+    uint32_t x;
+    // the ring row of the next read as an LDS address of its own: output #pos+1 now, stepped by 0x400 before every read -
+    // a 16-bit add, whose wrap at 2^16 IS the ring's wrap (64 rows of 1 KiB from LDS address 0): one instruction per draw
+    // where the position and its address took two; the position itself moves once, behind the loop
+    uint32_t a = ((rng.p10 + 0x400u) & 0xFC00u) | rng.lane_addr;
     uint64_t sv, cm, dm;
-    const uint32_t kMask = 0xFC00u, kSel = 0x0C000000u, kK = 0xFEFEFEFFu;
+    const uint32_t kSel = 0x0C000000u, kK = 0xFEFEFEFFu;
     asm volatile(
         "s_mov_b64 %[sv], exec\n\t"
         "v_cmp_ne_u32 vcc, 0, %[n]\n\t"
         "s_and_b64 exec, exec, vcc\n\t"
         "s_cbranch_execz 3f\n\t"
         "s_waitcnt lgkmcnt(0)\n\t"                         /* nothing but this loop's reads is counted below */
-        "v_mad_u64_u32 v[124:125], %[dm], %[o0], %[t], 0\n\t"
-        "v_add_u32 %[p10], 0x400, %[p10]\n"                /* the next read is output #pos+2 */
+        "v_mad_u64_u32 v[124:125], %[dm], %[o0], %[t], 0\n"
         "1:\n\t"
         MSE_RING_DRAW("v125", "v[126:127]", "o1", "o0", "")
         "s_cbranch_execz 2f\n\t"
@@ -920,17 +922,14 @@ __device__ __forceinline__ void draw_units_ring(RngRing &rng, uint32_t &C, int &
         "s_and_b64 exec, exec, vcc\n\t"                     /* the last f is not in the monitor yet             */
         "v_swap_b32 %[o0], %[o1]\n\t"
         "v_min_u32 %[mn], %[mn], v124\n\t"
-        "v_max_u32 %[mx], %[mx], v124\n\t"
-        "s_mov_b64 exec, %[sv]\n\t"
-        "v_cmp_ne_u32 vcc, 0, %[n]\n\t"                     /* lanes that drew at all ran p10 one ahead */
-        "s_and_b64 exec, exec, vcc\n\t"
-        "v_add_u32 %[p10], 0xfffffc00, %[p10]\n"
+        "v_max_u32 %[mx], %[mx], v124\n"
         "3:\n\t"
         "s_mov_b64 exec, %[sv]"
-        : [p10] "+v"(rng.p10), [x] "=&v"(x), [a] "=&v"(a), [o0] "+v"(rng.nxt), [o1] "+v"(rng.nxt2), [cb] "+v"(Cb),
+        : [x] "=&v"(x), [a] "+v"(a), [o0] "+v"(rng.nxt), [o1] "+v"(rng.nxt2), [cb] "+v"(Cb),
           [t] "+v"(T), [mn] "+v"(rng.f_min), [mx] "+v"(rng.f_max), [sv] "=&s"(sv), [cm] "=&s"(cm), [dm] "=&s"(dm)
-        : [sel] "s"(kSel), [mask] "s"(kMask), [lane] "v"(rng.lane_addr), [k] "s"(kK), [tend] "v"(T_end), [n] "v"(n_draws)
+        : [sel] "s"(kSel), [k] "s"(kK), [tend] "v"(T_end), [n] "v"(n_draws)
         : "vcc", "memory", "v124", "v125", "v126", "v127");
+    rng.p10 += n_draws << 10;
     C = Cb + 0x00808080u;
     rem = 0;
 #ifdef MSE_TIMELINE

@@ -1902,10 +1902,21 @@ __device__ __forceinline__ void env_dynamics(Env &e, RNG &rng, const Params &P, 
     int lvl[5];
 #pragma unroll
     for (int m = 0; m < 5; ++m) lvl[m] = level_of(e, m);
-    const PenaltyClass pc = classify_levels(lvl, P);
-    const bool overflowed = check_overflow && pc.any_cat; // a level above capacity
+    // Both lower brackets carry a penalty in the reference's config (wave-uniform flags): a step is then penalised iff
+    // SOME level is above the lowest threshold, i.e. iff the highest one is (thr_mild <= thr_sev <= capacity) - two
+    // three-way maxima and two compares where the bracket-by-bracket form takes fifteen compares
+    bool any_cat, penalised;
+    if (P.sev_negative && P.mild_negative) {
+        const int top = max(max(max(lvl[0], lvl[1]), max(lvl[2], lvl[3])), lvl[4]);
+        any_cat = top > P.capacity;
+        penalised = top > P.thr_mild;
+    } else {
+        const PenaltyClass pc = classify_levels(lvl, P);
+        any_cat = pc.any_cat;
+        penalised = pc.any_cat || (pc.any_sev && P.sev_negative) || (pc.any_mild && P.mild_negative);
+    }
+    const bool overflowed = check_overflow && any_cat; // a level above capacity
     if (KIND != 1 && !overflowed) {
-        const bool penalised = pc.any_cat || (pc.any_sev && P.sev_negative) || (pc.any_mild && P.mild_negative);
         if (!penalised) {
             e.lps = 0;
             e.lpa = 0;

@@ -942,13 +942,13 @@ __device__ __forceinline__ void draw_units_ring(RngRing &rng, uint32_t &C, int &
 // (round 2: 21): limb 1 is the low word of Y = s1 m0 + (s0 m1 + hi(s0 m0)) as ONE 64-bit multiply-add whose carry-out
 // (the 65th bit, an SGPR mask) joins limb 3 in the add that was there anyway - the upper word of Y then carries into
 // limbs 2..3 by one zero-extending move instead of two moves and a 64-bit add.  With the 7-instruction output, an
-// address in two and three of loop control: 32 per output.  Products and carries live in v[112:121].
+// address kept as a register that one 16-bit add advances (its wrap is the ring's) and three of loop control: 31 per output.  Products and carries live in v[112:121].
 __device__ __forceinline__ void ring_produce(Pcg &g, uint32_t &w, uint32_t count, uint32_t lane_addr)
 {
     uint32_t s0 = (uint32_t)g.s_lo, s1 = (uint32_t)(g.s_lo >> 32), s2 = (uint32_t)g.s_hi, s3 = (uint32_t)(g.s_hi >> 32);
     const uint32_t i0 = (uint32_t)g.i_lo, i1 = (uint32_t)(g.i_lo >> 32), i2 = (uint32_t)g.i_hi, i3 = (uint32_t)(g.i_hi >> 32);
-    const uint32_t m0 = 0x9FCCF645u, m1 = 0x4385DF64u, m2 = 0x1FC65DA4u, m3 = 0x2360ED05u, kMask = 0xFC00u;
-    uint32_t w10 = w << 10, left = count;
+    const uint32_t m0 = 0x9FCCF645u, m1 = 0x4385DF64u, m2 = 0x1FC65DA4u, m3 = 0x2360ED05u;
+    uint32_t a = ((w << 10) & 0xFC00u) | lane_addr, left = count; // LDS address of output #w's ring row
     uint32_t t0, t1, t2, t3, x, y;
     uint64_t sv, cm, dm, cy;
     asm volatile(
@@ -981,23 +981,21 @@ __device__ __forceinline__ void ring_produce(Pcg &g, uint32_t &w, uint32_t count
         "v_xor_b32 %[y], %[s1], %[s3]\n\t"
         "v_lshrrev_b32 %[t1], 26, %[s3]\n\t"
         "v_cmp_gt_i32 vcc, 0, %[s3]\n\t"
-        "v_and_or_b32 %[t0], %[w10], %[mask], %[lane]\n\t"
         "v_cndmask_b32 %[t2], %[x], %[y], vcc\n\t"
         "v_cndmask_b32 %[t3], %[y], %[x], vcc\n\t"
         "v_add_u32 %[left], -1, %[left]\n\t"
         "v_alignbit_b32 %[t2], %[t2], %[t3], %[t1]\n\t"
-        "v_add_u32 %[w10], 0x400, %[w10]\n\t"
         "v_cmp_ne_u32_e64 %[cm], 0, %[left]\n\t"
-        "ds_write_b32 %[t0], %[t2]\n\t"
+        "ds_write_b32 %[a], %[t2]\n\t"
+        "v_add_u16 %[a], 0x400, %[a]\n\t"                    /* next row; the 16-bit wrap is the ring's */
         "s_and_b64 exec, exec, %[cm]\n\t"
         "s_cbranch_execnz 1b\n"
         "3:\n\t"
         "s_mov_b64 exec, %[sv]"
-        : [s0] "+v"(s0), [s1] "+v"(s1), [s2] "+v"(s2), [s3] "+v"(s3), [w10] "+v"(w10), [left] "+v"(left), [t0] "=&v"(t0),
+        : [s0] "+v"(s0), [s1] "+v"(s1), [s2] "+v"(s2), [s3] "+v"(s3), [a] "+v"(a), [left] "+v"(left), [t0] "=&v"(t0),
           [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [x] "=&v"(x), [y] "=&v"(y), [sv] "=&s"(sv), [cm] "=&s"(cm),
           [dm] "=&s"(dm), [cy] "=&s"(cy)
-        : [i0] "v"(i0), [i1] "v"(i1), [i2] "v"(i2), [i3] "v"(i3), [m0] "s"(m0), [m1] "s"(m1), [m2] "s"(m2), [m3] "s"(m3),
-          [mask] "s"(kMask), [lane] "v"(lane_addr)
+        : [i0] "v"(i0), [i1] "v"(i1), [i2] "v"(i2), [i3] "v"(i3), [m0] "s"(m0), [m1] "s"(m1), [m2] "s"(m2), [m3] "s"(m3)
         : "vcc", "memory", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121");
     g.s_lo = (uint64_t)s0 | ((uint64_t)s1 << 32);
     g.s_hi = (uint64_t)s2 | ((uint64_t)s3 << 32);
@@ -1017,9 +1015,9 @@ __device__ __forceinline__ void ring_produce_pairs(Pcg &g, uint32_t &w, uint32_t
     uint32_t s0 = (uint32_t)g.s_lo, s1 = (uint32_t)(g.s_lo >> 32), s2 = (uint32_t)g.s_hi, s3 = (uint32_t)(g.s_hi >> 32);
     const uint32_t i0 = (uint32_t)g.i_lo, i1 = (uint32_t)(g.i_lo >> 32), i2 = (uint32_t)g.i_hi, i3 = (uint32_t)(g.i_hi >> 32);
     const uint32_t j0 = (uint32_t)c2_lo, j1 = (uint32_t)(c2_lo >> 32), j2 = (uint32_t)c2_hi, j3 = (uint32_t)(c2_hi >> 32);
-    const uint32_t m0 = 0x9FCCF645u, m1 = 0x4385DF64u, m2 = 0x1FC65DA4u, m3 = 0x2360ED05u, kMask = 0xFC00u;
+    const uint32_t m0 = 0x9FCCF645u, m1 = 0x4385DF64u, m2 = 0x1FC65DA4u, m3 = 0x2360ED05u;
     const uint32_t n0 = 0x20E0AE99u, n1 = 0x529ED9EBu, n2 = 0xDF69743Cu, n3 = 0x17BCE35Bu; // M^2 mod 2^128
-    uint32_t w10 = w << 10, left = pairs;
+    uint32_t a = ((w << 10) & 0xFC00u) | lane_addr, left = pairs; // LDS address of output #w's ring row
     uint64_t sv, cm, dm, cy, cy2;
     asm volatile(
         "s_mov_b64 %[sv], exec\n\t"
@@ -1079,25 +1077,22 @@ __device__ __forceinline__ void ring_produce_pairs(Pcg &g, uint32_t &w, uint32_t
         "v_cndmask_b32_e64 v96, v98, v99, %[cm]\n\t"
         "v_cndmask_b32 v125, v127, v126, vcc\n\t"
         "v_cndmask_b32_e64 v97, v99, v98, %[cm]\n\t"
-        "v_and_or_b32 v122, %[w10], %[mask], %[lane]\n\t"
-        "v_add_u32 %[w10], 0x400, %[w10]\n\t"
         "v_alignbit_b32 v124, v124, v125, v123\n\t"
         "v_alignbit_b32 v96, v96, v97, v95\n\t"
-        "v_and_or_b32 v94, %[w10], %[mask], %[lane]\n\t"
-        "v_add_u32 %[left], -1, %[left]\n\t"
-        "v_add_u32 %[w10], 0x400, %[w10]\n\t"
-        "ds_write_b32 v122, v124\n\t"
+        "v_add_u16 v94, 0x400, %[a]\n\t"                     /* the second output's row: a 16-bit add, whose wrap is */
+        "v_add_u32 %[left], -1, %[left]\n\t"                 /* the ring's (64 rows of 1 KiB from LDS address 0)    */
+        "ds_write_b32 %[a], v124\n\t"
         "v_cmp_ne_u32_e64 %[cm], 0, %[left]\n\t"
         "ds_write_b32 v94, v96\n\t"
+        "v_add_u16 %[a], 0x400, v94\n\t"
         "s_and_b64 exec, exec, %[cm]\n\t"
         "s_cbranch_execnz 1b\n"
         "3:\n\t"
         "s_mov_b64 exec, %[sv]"
-        : [s0] "+v"(s0), [s1] "+v"(s1), [s2] "+v"(s2), [s3] "+v"(s3), [w10] "+v"(w10), [left] "+v"(left), [sv] "=&s"(sv),
+        : [s0] "+v"(s0), [s1] "+v"(s1), [s2] "+v"(s2), [s3] "+v"(s3), [a] "+v"(a), [left] "+v"(left), [sv] "=&s"(sv),
           [cm] "=&s"(cm), [dm] "=&s"(dm), [cy] "=&s"(cy), [cy2] "=&s"(cy2)
         : [i0] "v"(i0), [i1] "v"(i1), [i2] "v"(i2), [i3] "v"(i3), [j0] "v"(j0), [j1] "v"(j1), [j2] "v"(j2), [j3] "v"(j3),
-          [m0] "s"(m0), [m1] "s"(m1), [m2] "s"(m2), [m3] "s"(m3), [n0] "s"(n0), [n1] "s"(n1), [n2] "s"(n2), [n3] "s"(n3),
-          [mask] "s"(kMask), [lane] "v"(lane_addr)
+          [m0] "s"(m0), [m1] "s"(m1), [m2] "s"(m2), [m3] "s"(m3), [n0] "s"(n0), [n1] "s"(n1), [n2] "s"(n2), [n3] "s"(n3)
         : "vcc", "memory", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103",
           "v104", "v105", "v106", "v107", "v108", "v109", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120",
           "v121", "v122", "v123", "v124", "v125", "v126", "v127");

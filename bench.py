@@ -424,7 +424,12 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        kw = dict(rank=rank, world_size=world) if forced else {}
+        import datetime
+
+        # every collective of this script is short: a stuck one should end the run in minutes, not at the default
+        kw = dict(timeout=datetime.timedelta(minutes=4))
+        if forced:
+            kw.update(rank=rank, world_size=world)
         if rehearsal:
             dist.init_process_group(backend="gloo", **kw)
         else:

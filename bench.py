@@ -126,11 +126,11 @@ def profiled(kind, n, noise, policy, steps_per_launch, key):
     return None
 
 
-def kernel_name(kind, n, policy, pipeline, mode, cus=256):
+def kernel_name(kind, n, policy, pipeline, mode, cus=256, precision="f16x3"):
     if mode == "step":
         return "k_sample + k_step"
-    if policy == "mlp":
-        return "k_rollout_policy"
+    if policy == "mlp":  # the library's rule (launch_rollout_policy): roles while a SIMD gets 64 envs, f16x3 form only
+        return "k_rollout_policy_roles" if n <= 256 * cus and pipeline != 2 and precision != "f32" else "k_rollout_policy"
     wgs = -(-n // 256)   # the library's rule (mse_create): one round of 256-env workgroups, or most of a second one
     by_size = wgs <= cus or (cus + cus // 4 < wgs <= 2 * cus)
     return {1: "k_rollout_po", 2: "k_rollout", 3: "k_rollout_ring"}.get(pipeline, "k_rollout_ring" if by_size else "k_rollout")
@@ -245,7 +245,8 @@ def roofline_of(wl, steps, reps, event_ms):
         "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
         "fused_bytes_per_env_step": fused,
         "traffic": None if wl.no_outputs else profiled(wl.kind, wl.n, wl.noise, wl.policy, spl, "hbm_bytes_per_launch"),
-        "kernel": kernel_name(wl.kind, wl.n, wl.policy, wl.pipeline, wl.mode),
+        "kernel": kernel_name(wl.kind, wl.n, wl.policy, wl.pipeline, wl.mode,
+                              precision=wl.collector.policy.precision if wl.policy == "mlp" else "f16x3"),
         "launch_ms": per_launch_ms, "env_steps_per_launch": wl.n * spl,
         # SURVEY 8d's per-step contract (state read + written EVERY step): a fused launch does not move those bytes,
         # so this figure can pass 1.0 on long launches of large batches - kept for comparison only

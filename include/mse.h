@@ -102,6 +102,9 @@ typedef struct mse_config {
        n <= 256 x CUs - or fills most of a second one, 320 x CUs < n <= 512 x CUs -, the multi-role kernels:
        dynamics + observer waves, plus RNG waves when the config's draws per step fit the ring; otherwise one lane
        per env), 1 = dynamics + observer waves, 2 = one lane per env, 3 = dynamics + observer + RNG waves.
+       mse_rollout_policy reads the same field: up to 256 envs x CUs (f16x3 products, no in-loop sorting policy) it
+       runs actor + critic + RNG waves per 64 envs (0, when the draws fit the ring), actor + critic waves (1, or 0 when
+       they do not) or one wave per 32 envs doing everything (2); above that size 64-env waves whatever the value.
        Results are identical. */
     int32_t  rollout_pipeline;
     int32_t  reserved0;

@@ -716,7 +716,8 @@ struct RingLayout {
 // first one (B_init) publishes the ring's priming, B_s the outputs step s + 1 may consume; lpos[el] is the consumer's
 // count after step s.  two_halves: the consumer side's idle lanes have produced [worst, 2 worst) before B_init.
 __device__ __forceinline__ void rng_server_role(const Params &P, uint4 *__restrict__ planes, const Tables &tb, long long i,
-                                                bool live, int k_steps, uint32_t *lring, uint32_t *lpos, int el, bool two_halves)
+                                                bool live, int k_steps, uint32_t *lring, uint32_t *lpos, int el, bool two_halves,
+                                                int barriers_before_init = 0)
 {
     Pcg g;
     {
@@ -778,6 +779,8 @@ __device__ __forceinline__ void rng_server_role(const Params &P, uint4 *__restri
         }
 #endif
         MSE_TLB(tl, 0);
+        if (s < 0) // (k_rollout_policy_roles: the workgroup's prologue barrier comes before B_init; lpos is set behind it)
+            for (int b = 0; b < barriers_before_init; ++b) lds_barrier_all();
         lds_barrier_all(); // s == -1: B_init (first outputs are in place); else B_s
         MSE_TLB(tl, 1);
         if (s < 0 && two_halves) {
@@ -1100,15 +1103,10 @@ __device__ __forceinline__ uint32_t lds_row_address(const void *row)
     return a;
 }
 
+// a finished tile of ROWS observation rows (D floats each, row-major) in LDS to global memory as 16-byte pieces
 template <int D, int ROWS>
-__device__ __forceinline__ void wave_store_rows_f32(float *ltile, uint32_t lrow, const float *o, float *g, int n_valid, int lane)
+__device__ __forceinline__ void wave_tile_to_global_f32(const float *ltile, float *g, int n_valid, int lane)
 {
-    if (lane < ROWS) {
-        lds_f32 *row = (lds_f32 *)(uintptr_t)lrow; // = ltile + lane * D
-#pragma unroll
-        for (int j = 0; j < D; ++j) row[j] = o[j];
-    }
-    __builtin_amdgcn_wave_barrier();
     constexpr int NQ = ROWS * D / 4; // 16-byte pieces of a full tile
     if (n_valid == ROWS && (reinterpret_cast<uintptr_t>(g) & 15u) == 0) {
         const float4 *src = reinterpret_cast<const float4 *>(ltile);
@@ -1123,6 +1121,17 @@ __device__ __forceinline__ void wave_store_rows_f32(float *ltile, uint32_t lrow,
     } else {
         for (int q = lane; q < n_valid * D; q += 64) g[q] = ltile[q];
     }
+}
+template <int D, int ROWS>
+__device__ __forceinline__ void wave_store_rows_f32(float *ltile, uint32_t lrow, const float *o, float *g, int n_valid, int lane)
+{
+    if (lane < ROWS) {
+        lds_f32 *row = (lds_f32 *)(uintptr_t)lrow; // = ltile + lane * D
+#pragma unroll
+        for (int j = 0; j < D; ++j) row[j] = o[j];
+    }
+    __builtin_amdgcn_wave_barrier();
+    wave_tile_to_global_f32<D, ROWS>(ltile, g, n_valid, lane);
     __builtin_amdgcn_wave_barrier();
 }
 template <int A, int ROWS>
@@ -1331,6 +1340,300 @@ __global__ __launch_bounds__(512) void k_rollout_policy(Params P, uint4 *__restr
     if (P.track_bales && live) {
 #pragma unroll
         for (int m = 0; m < 5; ++m) planes[(long long)(PL_BALE0 + m) * P.n_pad + i] = lbale[m * ENVS + lane];
+    }
+}
+
+// ---- the learned-policy rollout in roles (batches that leave a SIMD 64 envs: n <= 256 envs x CUs) --------------------
+// k_rollout_policy at that size has to choose between one 64-env wave per SIMD, alone with its own latencies, and two
+// 32-env waves that issue the env transition twice with half their lanes mirroring.  Here a SIMD's 64 envs are one full
+// ACTOR wave - actor network, sampling, env transition: the serial chain of a step, nothing else - and beside it
+//   a CRITIC wave that takes what the chain does not wait for: the value network, the observation / mask / episode-start
+//     rows of the rollout buffer and, after the last step, the bootstrap value;
+//   RING = true: an RNG wave that runs the envs' sort_material streams ahead into the LDS ring of k_rollout_ring (same
+//     protocol, same device functions: rng_server_role on one side, env_dynamics on RngRing on the other), which takes
+//     the 128-bit LCG steps - a long dependent chain - out of the actor wave.  Needs what the ring kernel needs (at
+//     most kRingMaxPerStep draws per step, the ring at LDS address 0); else RING = false.
+// Workgroup = four actor waves, four critic waves[, four RNG waves]; waves p, p + 4[, p + 8] serve the same 64 envs and
+// meet on SIMD p.  The actor wave posts each step's observation rows and mask word into the pair's LDS tile before the
+// step's barrier; the critic wave reads the MFMA operands and the rows' 16-byte pieces from it after the barrier, all at
+// once, and then raises the tile's `taken` count, which the actor wave checks before it posts the next row (it never
+// has to wait: the next post is a whole step away).  One barrier per step, shared with the ring's flow control.
+// Same device functions as k_rollout_policy (actor_tiles and value_tiles are policy_tiles' two networks; env_step is
+// env_dynamics + env_observe), so every buffer is bit-identical to it and to the two-launch collector.
+template <int KIND, bool RING>
+struct PolRolesLayout {
+    static constexpr int D = Dims<KIND>::D, A = Dims<KIND>::A;
+    static constexpr int kPairs = 4, kThreads = 64 * kPairs * (RING ? 3 : 2);
+    static_assert(64 * kPairs == kPoEnvs, "the ring has one column per env of the workgroup");
+    static constexpr int ring_bytes = RING ? kRingDepth * kPoEnvs * 4 : 0; // at LDS address 0 (RngRing::load)
+    static constexpr int weight_offset = ring_bytes;
+    static constexpr int weight_bytes = msep::kLdsFloats * 4;
+    static constexpr int pos_offset = weight_offset + weight_bytes;
+    static constexpr int pos_bytes = RING ? kPoEnvs * 4 : 0;
+    static constexpr int taken_offset = pos_offset + pos_bytes;     // rows the critic wave has taken out of the tile: u32[kPairs]
+    static constexpr int pair_offset = taken_offset + 16;
+    static constexpr int tile_bytes = (64 * D * 4 + 15) / 16 * 16;
+    static constexpr int mword_bytes = 64 * 4;                     // action-mask bits | episode-start flag << 31
+    static constexpr int mask_bytes = (64 * A + 15) / 16 * 16;     // the critic wave's staging tile of mask rows
+    static constexpr int bale_bytes = 5 * 64 * 16;
+    static constexpr int pair_bytes = tile_bytes + mword_bytes + mask_bytes + bale_bytes;
+    static constexpr int table_offset = pair_offset + kPairs * pair_bytes; // multiple of 16
+};
+
+#ifndef MSE_ROLES_PRIO
+#define MSE_ROLES_PRIO 3
+#endif
+template <int KIND, bool NOISE, bool RING>
+__global__ __launch_bounds__(RING ? 768 : 512) void k_rollout_policy_roles(Params P, uint4 *__restrict__ planes,
+                                                                           const uint32_t *__restrict__ table_image,
+                                                                           const float *__restrict__ weight_blob, int k_steps,
+                                                                           uint64_t policy_seed, uint64_t policy_t0, int deterministic,
+                                                                           const int *__restrict__ sort_mode, uint32_t flags,
+                                                                           float *__restrict__ obs_out, uint8_t *__restrict__ mask_out,
+                                                                           int *__restrict__ actions_out, float *__restrict__ logp_out,
+                                                                           float *__restrict__ value_out, float *__restrict__ reward_out,
+                                                                           uint8_t *__restrict__ start_out,
+                                                                           float *__restrict__ last_value_out,
+                                                                           uint8_t *__restrict__ last_done_out)
+{
+    using L = PolRolesLayout<KIND, RING>;
+    constexpr int D = L::D, A = L::A, NR = msep::regs_for_actions(A);
+    static_assert(A < 31, "the mask word keeps bit 31 for the episode-start flag");
+    uint8_t *lds = reinterpret_cast<uint8_t *>(mse_dyn_lds);
+    float *lw = reinterpret_cast<float *>(lds + L::weight_offset);
+    uint32_t *ltab = reinterpret_cast<uint32_t *>(lds + L::table_offset);
+    uint32_t *lring = reinterpret_cast<uint32_t *>(lds);
+    uint32_t *lpos = reinterpret_cast<uint32_t *>(lds + L::pos_offset);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int pair = wave & (L::kPairs - 1), role = wave / L::kPairs; // wave-uniform: 0 actor, 1 critic, 2 RNG
+    const int el = pair * 64 + lane;                                  // env slot inside the workgroup
+    volatile uint32_t *ltaken = reinterpret_cast<volatile uint32_t *>(lds + L::taken_offset) + pair;
+    uint8_t *lpair = lds + L::pair_offset + pair * L::pair_bytes;
+    float *ltile = reinterpret_cast<float *>(lpair);                              // [64][D]
+    uint32_t *lmword = reinterpret_cast<uint32_t *>(lpair + L::tile_bytes);       // [64]
+    uint8_t *lmask = lpair + L::tile_bytes + L::mword_bytes;
+    uint4 *lbale = reinterpret_cast<uint4 *>(lmask + L::mask_bytes);
+    const long long wave_row0 = ((long long)blockIdx.x * L::kPairs + pair) * 64;
+    const long long rem = P.n - wave_row0;
+    const int n_valid = rem >= 64 ? 64 : (rem > 0 ? (int)rem : 0);
+    const bool pair_active = n_valid > 0;
+    // every lane of an active pair steps an env: lanes past the batch's end mirror its last env and store nothing
+    const bool live = pair_active && wave_row0 + lane < P.n;
+    const long long i = pair_active ? (wave_row0 + lane < P.n ? wave_row0 + lane : P.n - 1) : 0;
+
+    const Tables tb = tables_at(ltab, P);
+    if (RING && role == 2) {
+        // The RNG waves start priming the ring at once (they read no table before the end of the launch) while the other
+        // waves bring the weight and table images and the env state in; rng_server_role meets them at the prologue's
+        // barrier and then at the k_steps + 1 step barriers: B_init = the one before step 0, B_s = the one before step s + 1.
+        if (pair_active) rng_server_role(P, planes, tb, i, live, k_steps, lring, lpos, el, false, /*barriers_before_init=*/1);
+        else for (int s = -1; s <= k_steps; ++s) lds_barrier_all();
+        return;
+    }
+    msep_copy_image(lw, weight_blob, true, tid, 128 * L::kPairs); // actor and critic waves: tid < 128 kPairs
+    for (int w = tid; w < P.table_words / 4; w += 128 * L::kPairs)
+        reinterpret_cast<uint4 *>(ltab)[w] = reinterpret_cast<const uint4 *>(table_image)[w];
+    const BaleRef bales{lbale + lane, 64};
+    Env e;
+    int sm = -1;
+    if (role == 0) {
+        if (P.track_bales && pair_active) {
+#pragma unroll
+            for (int m = 0; m < 5; ++m) lbale[m * 64 + lane] = planes[(long long)(PL_BALE0 + m) * P.n_pad + i];
+        }
+        load_env<KIND, NOISE>(e, planes, P, i);
+        if (KIND == 2 && sort_mode != nullptr) sm = sort_mode[i];
+        if (lane == 0) *ltaken = 0u;
+        if (RING) lpos[el] = 0u;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // nothing but stores inside the step loop
+    lds_barrier_all();                                 // the images, lpos and `taken` are in place
+    if (!pair_active) { // the step barriers count every wave of the workgroup
+        for (int s = 0; s <= k_steps; ++s) lds_barrier_all();
+        return;
+    }
+    msep::lds_f4 wl = (msep::lds_f4)(__attribute__((address_space(3))) float *)lw;
+    const int h = lane >> 5, col = lane & 31;
+
+    if (role == 0) {
+        __builtin_amdgcn_s_setprio(MSE_ROLES_PRIO); // the chain of the step: ahead of the other waves whenever several can issue
+        float o[32];
+#pragma unroll
+        for (int j = 0; j < 32; ++j) o[j] = 0.0f;
+        int kcur[4];
+        container_purity_k(e, kcur);
+        env_obs<KIND>(e, P, tb, kcur, o);
+        uint32_t mbits = action_mask_bits<KIND>(e, P);
+        const uint32_t key0 = mse_policy_key(policy_seed, (uint64_t)(P.index_offset + wave_row0 + col));
+        const uint32_t key1 = mse_policy_key(policy_seed, (uint64_t)(P.index_offset + wave_row0 + 32 + col));
+        auto legal_of = [&](uint32_t env_bits) -> uint32_t { // as in k_rollout_policy
+            const uint32_t t = env_bits >> (4 * h);
+            return (t & 0xFu) | ((t >> 4) & 0xF0u) | ((t >> 8) & 0xF00u) | ((t >> 12) & 0xF000u);
+        };
+        RngRing ring;
+        if (RING) { // as the dynamics role of k_rollout_ring
+            ring.lane_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)(lring + el);
+            ring.jump_tab = tb.jump;
+            ring.start = e.rng;
+            ring.p10 = 0;
+            ring.nxt = ring.nxt2 = 0;
+            ring.f_min = 0xFFFFFFFFu;
+            ring.f_max = 0u;
+#ifdef MSE_TIMELINE
+            ring.tl = &e.tl;
+#endif
+        }
+        const uint32_t lrow = lds_row_address(ltile + lane * D);
+        // `taken` is read a phase early (its LDS round trip rides under the observation's arithmetic) and again only if
+        // the critic wave had not got to the tile by then, which a whole actor network + env transition makes unlikely
+        uint32_t taken = 0;
+        auto post_row = [&](int s) { // the state the coming action is taken from: row s of the rollout buffer
+            while (__builtin_amdgcn_readfirstlane(taken) < (uint32_t)s) { // row s - 1 is out of the tile
+                __builtin_amdgcn_s_sleep(1);
+                taken = *ltaken;
+            }
+            lds_f32 *row = (lds_f32 *)(uintptr_t)lrow;
+#pragma unroll
+            for (int j = 0; j < D; ++j) row[j] = o[j];
+            lmword[lane] = mbits | (e.step == 0 ? 0x80000000u : 0u);
+        };
+        int last_done = 0;
+#ifdef MSE_TIMELINE
+        e.tl.start();
+#endif
+        for (int s = 0; s < k_steps; ++s) {
+            post_row(s);
+            MSE_TLB(e.tl, 5); // observation, auto-reset, mask, per-env stores, the row's post
+            lds_barrier_all();
+            MSE_TLB(e.tl, 6); // barrier wait
+            float x[2][16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(o[2 * q]), __float_as_uint(o[2 * q + 1]), false, false);
+                x[0][q] = __uint_as_float(r[0]);
+                x[1][q] = __uint_as_float(r[1]);
+            }
+            uint32_t mb0, mb1;
+            msep::both_halves_u32((flags & MSE_STEP_UNMASKED) ? ((1u << A) - 1u) : mbits, mb0, mb1);
+            const uint64_t t = policy_t0 + (uint64_t)s;
+            const uint32_t legal[2] = {legal_of(mb0), legal_of(mb1)};
+            const uint32_t words[2] = {mse_policy_word(key0, t), mse_policy_word(key1, t)};
+            msep::TileOut p[2];
+            msep::actor_tiles<NR, true, 2>(wl, lane, x, legal, deterministic != 0, words, p);
+            const int a = h ? p[1].action : p[0].action; // lane l is env l: tile l >> 5, column l & 31
+            const float logp = h ? p[1].logp : p[0].logp;
+            MSE_TLB(e.tl, 0); // actor network and sampling
+            StepResult r;
+            if (RING) {
+                Snap sn;
+                env_dynamics<KIND, NOISE, false>(e, ring, P, tb, a, sm, flags, bales, sn);
+                taken = *ltaken;
+                r = env_observe<KIND, NOISE>(sn, P, tb, kcur, o);
+            } else {
+                taken = *ltaken;
+                r = env_step<KIND, NOISE, false>(e, P, tb, a, sm, flags, bales, kcur, o);
+            }
+            if (__builtin_expect(r.done != 0, 0)) {
+                auto_reset_env(e, P, tb, bales, kcur);
+                env_obs<KIND>(e, P, tb, kcur, o);
+            }
+            mbits = action_mask_bits<KIND>(e, P);
+            last_done = r.done;
+            if (RING) lpos[el] = ring.pos(); // what the env has consumed: the RNG lane reads it after the next barrier
+            if (live) {
+                const long long at = (long long)s * P.n + i;
+                if (actions_out != nullptr) __builtin_nontemporal_store(a, &actions_out[at]);
+                if (logp_out != nullptr) __builtin_nontemporal_store(logp, &logp_out[at]);
+                if (reward_out != nullptr) __builtin_nontemporal_store((float)r.reward, &reward_out[at]);
+            }
+        }
+        post_row(k_steps); // the state the rollout ends in, for the bootstrap value
+        lds_barrier_all();
+#ifdef MSE_TIMELINE
+        e.tl.flush(0);
+#endif
+        if (live && last_done_out != nullptr) last_done_out[i] = (uint8_t)last_done;
+        // (RING: the generator state is written by the RNG lane, which steps back to the consumed position)
+        if (live) store_env<KIND, NOISE>(e, planes, P, i, false, /*write_rng_state=*/!RING);
+        if (P.track_bales && live) {
+#pragma unroll
+            for (int m = 0; m < 5; ++m) planes[(long long)(PL_BALE0 + m) * P.n_pad + i] = lbale[m * 64 + lane];
+        }
+        return;
+    }
+
+    // ---- critic wave
+    const uint32_t lrow_mask = lds_row_address(lmask + lane * A);
+    constexpr int NQ = 64 * D / 4, NP = (NQ + 63) / 64; // 16-byte pieces of the tile, per lane
+    // everything of a posted row set in one go: the layer-1 operands of this lane (register q of tile t = entry 2 q + h
+    // of env 32 t + col), the rows as 16-byte pieces, the mask word; then the tile is the actor wave's again
+    auto take_tile = [&](int s, float (*x)[16], float4 *piece, uint32_t &mw) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const float *row = ltile + (32 * t + col) * D;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                if (2 * q + 1 < D) x[t][q] = row[2 * q + h];
+                else if (2 * q < D) x[t][q] = h ? 0.0f : row[2 * q];
+                else x[t][q] = 0.0f;
+            }
+        }
+        if (piece != nullptr) {
+#pragma unroll
+            for (int j = 0; j < NP; ++j) piece[j] = reinterpret_cast<const float4 *>(ltile)[(lane + 64 * j) < NQ ? lane + 64 * j : 0];
+        }
+        mw = lmword[lane];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the reads have returned
+        if (lane == 0) *ltaken = (uint32_t)(s + 1);
+    };
+#ifdef MSE_TIMELINE
+    Timeline ctl;
+    ctl.start();
+#endif
+    for (int s = 0; s < k_steps; ++s) {
+        lds_barrier_all();
+        MSE_TLB(ctl, 0); // barrier wait
+        float x[2][16];
+        float4 piece[NP];
+        uint32_t mw;
+        take_tile(s, x, piece, mw);
+        MSE_TLB(ctl, 1); // tile -> registers
+        const long long srow = (long long)s * P.n + wave_row0;
+        if (obs_out != nullptr) {
+            float *g = obs_out + srow * D;
+            if (n_valid == 64 && (reinterpret_cast<uintptr_t>(g) & 15u) == 0) { // whole pieces (a ragged batch's later rows start anywhere)
+#pragma unroll
+                for (int j = 0; j < NP; ++j)
+                    if (lane + 64 * j < NQ) store_stream(reinterpret_cast<float4 *>(g) + lane + 64 * j, piece[j]);
+            } else { // entry by entry out of the pieces
+#pragma unroll
+                for (int j = 0; j < NP; ++j) {
+                    const int q0 = 4 * (lane + 64 * j);
+                    const float v4[4] = {piece[j].x, piece[j].y, piece[j].z, piece[j].w};
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        if (q0 + c < n_valid * D) g[q0 + c] = v4[c];
+                }
+            }
+        }
+        if (mask_out != nullptr) wave_store_rows_mask<A, 64>(lmask, lrow_mask, mw & 0x7FFFFFFFu, mask_out + srow * A, n_valid, lane);
+        if (live && start_out != nullptr) __builtin_nontemporal_store((uint8_t)(mw >> 31), &start_out[(long long)s * P.n + i]);
+        MSE_TLB(ctl, 2); // row stores
+        float v[2];
+        msep::value_tiles<true, 2>(wl, lane, x, v);
+        if (live && value_out != nullptr) __builtin_nontemporal_store(h ? v[1] : v[0], &value_out[(long long)s * P.n + i]);
+        MSE_TLB(ctl, 3); // value network
+    }
+#ifdef MSE_TIMELINE
+    ctl.flush(1);
+#endif
+    lds_barrier_all();
+    if (last_value_out != nullptr) {
+        float x[2][16], v[2];
+        uint32_t mw;
+        take_tile(k_steps, x, nullptr, mw);
+        msep::value_tiles<true, 2>(wl, lane, x, v);
+        if (live) last_value_out[i] = h ? v[1] : v[0];
     }
 }
 
@@ -1682,6 +1985,7 @@ struct mse_env {
     bool literal;                // evaluate every Generator.choice draw in literal fp64
     bool pipelined;              // mse_rollout uses the dynamics/observer kernel (k_rollout_po)
     bool ring;                   // ... with RNG waves feeding an LDS ring (k_rollout_ring)
+    bool ring_ok;                // the config allows an LDS ring at all (draws per step, integer draw path, build)
     uint64_t policy_t;
     // opt-in trace of one env (mse_trace_begin): records_dev f64[capacity][MSE_TRACE_COLS], caller-owned
     double *trace_rec;
@@ -1967,7 +2271,10 @@ static bool ring_kernels_static_lds_free()
     if (cached < 0) {
         const void *fns[] = {(const void *)k_rollout_ring<1, false>, (const void *)k_rollout_ring<1, true>,
                              (const void *)k_rollout_ring<2, false>, (const void *)k_rollout_ring<2, true>,
-                             (const void *)k_rollout_ring<3, false>, (const void *)k_rollout_ring<3, true>};
+                             (const void *)k_rollout_ring<3, false>, (const void *)k_rollout_ring<3, true>,
+                             (const void *)k_rollout_policy_roles<1, false, true>, (const void *)k_rollout_policy_roles<1, true, true>,
+                             (const void *)k_rollout_policy_roles<2, false, true>, (const void *)k_rollout_policy_roles<2, true, true>,
+                             (const void *)k_rollout_policy_roles<3, false, true>, (const void *)k_rollout_policy_roles<3, true, true>};
         cached = 1;
         for (const void *f : fns) {
             hipFuncAttributes a{};
@@ -2056,6 +2363,30 @@ static int launch_rollout_policy(mse_env *h, const mse_policy *pol, const mse_po
     // instruction per ~5 cycles; beyond, 64 envs.  The exact-f32 form only exists in the 64-env shape.
     const int cus = h->cus; // queried once at create: hipGetDeviceProperties is far too slow for a launch path
     const bool f16 = pol->use_f16();
+    // Batches that leave a SIMD 64 envs (n <= 256 envs x CUs), f16x3 form, no in-loop sorting policy: the two-role
+    // kernel in roles (one workgroup of four actor / critic[ / RNG] wave sets per 256 envs).  rollout_pipeline = 2 ("one
+    // lane per env, no roles") keeps the plain kernel and 1 ("two roles") the form without the RNG waves, which is how the
+    // tests hold the three against each other.
+    if (f16 && sort_pol == nullptr && h->P.n <= (long long)256 * cus && h->cfg.rollout_pipeline != 2) {
+        const size_t table_bytes = (size_t)h->P.table_words * 4u;
+        const size_t lds_ring = (size_t)PolRolesLayout<KIND, true>::table_offset + table_bytes;
+        const size_t lds_pair = (size_t)PolRolesLayout<KIND, false>::table_offset + table_bytes;
+        const bool with_ring = h->ring_ok && lds_ring <= (size_t)160 * 1024 && h->cfg.rollout_pipeline != 1;
+        if (with_ring || lds_pair <= (size_t)160 * 1024) {
+            const dim3 grid_r((unsigned)((h->P.n + kPoEnvs - 1) / kPoEnvs));
+#define MSE_LAUNCH_RPR(NOISE, RING)                                                                                  \
+    hipLaunchKernelGGL((k_rollout_policy_roles<KIND, NOISE, RING>), grid_r, dim3((unsigned)PolRolesLayout<KIND, RING>::kThreads), \
+                       (RING ? lds_ring : lds_pair), s, h->P, h->planes, h->tables, pol->blob, k_steps, seed, h->policy_t,   \
+                       deterministic, sort_mode, flags, obs, mask, actions, logp, value, rew, start, last_value, last_done)
+            if (with_ring) {
+                if (h->noise_on) MSE_LAUNCH_RPR(true, true); else MSE_LAUNCH_RPR(false, true);
+            } else {
+                if (h->noise_on) MSE_LAUNCH_RPR(true, false); else MSE_LAUNCH_RPR(false, false);
+            }
+#undef MSE_LAUNCH_RPR
+            return MSE_OK;
+        }
+    }
     const int tiles = (f16 && h->P.n <= (long long)256 * cus) ? 1 : 2;
     // (the exact-f32 form below that size: four 64-env waves per workgroup, so that every CU gets one)
     const int n_waves = (!f16 && h->P.n <= (long long)256 * cus) ? 4 : 8;
@@ -2315,6 +2646,7 @@ int mse_create_indexed(mse_env **out, const mse_config *cfg, int64_t n_envs, int
         else ring_lds += nz ? RingLayout<3, true>::table_offset : RingLayout<3, false>::table_offset;
         P.ring_worst = worst;
         set_ring_forward_jump(P);
+        h->ring_ok = worst <= kRingMaxPerStep && !h->literal && !P.gen_mode && ring_kernels_static_lds_free();
         const bool fits = worst <= kRingMaxPerStep && !h->literal && ring_lds <= (size_t)160 * 1024 && ring_kernels_static_lds_free();
         // (the second-round rule above was measured with the three-role kernel only)
         if (cfg->rollout_pipeline == 0 && n_wg > cus && !fits) h->pipelined = false;

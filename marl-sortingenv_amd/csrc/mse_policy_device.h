@@ -404,6 +404,38 @@ __device__ __forceinline__ void actor_argmax2_tiles(lds_f4 wl, int lane, const f
     }
 }
 
+// The actor alone with policy_tiles' masked sampling, for T tiles: the action half of the two-role policy rollout
+// (mse_lib.hip: k_rollout_policy_roles), whose critic runs on a partner wave.  Same layers, same bits as policy_tiles;
+// out[t].value is left alone.
+template <int NR, bool F16X3, int T>
+__device__ __forceinline__ void actor_tiles(lds_f4 wl, int lane, const float (*x)[16], const uint32_t *legal, bool deterministic,
+                                            const uint32_t *word, TileOut *out)
+{
+    const int h = lane >> 5;
+    Operands<F16X3, T> xin, op;
+#pragma unroll
+    for (int t = 0; t < T; ++t) xin.set(t, x[t]);
+    float hid[16];
+    f32x16 acc[T], acc2[T], lg[T];
+    apply_layer<T>(wl, lane, h, 0, xin, acc);
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) hid[r] = sigmoid2(acc[t][r]);
+        op.set(t, hid);
+    }
+    apply_layer<T>(wl, lane, h, 1, op, acc2);
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) hid[r] = sigmoid2(acc2[t][r]);
+        op.set(t, hid);
+    }
+    apply_layer<T>(wl, lane, h, 2, op, lg);
+#pragma unroll
+    for (int t = 0; t < T; ++t) sample_tile<NR>(lg[t], h, legal[t], deterministic, word[t], nullptr, out[t]);
+}
+
 // The critic alone for T tiles: the bootstrap value of the state a rollout ends in.  Same layers, same bits as
 // policy_tiles (a network's operations do not depend on what runs beside them).
 template <bool F16X3, int T>

@@ -255,6 +255,38 @@ def test_fused_policy_rollout_equals_two_launch_collector(kind, noise, n, K, pre
     assert torch.equal(x["actions"], y["actions"]) and torch.equal(x["rewards"], y["rewards"])
 
 
+@pytest.mark.parametrize("pipeline", [1, 2])
+@pytest.mark.parametrize("kind,noise,n,K,flags", [("mono", 0.0, 5000, 24, 0), ("mono", 0.05, 777, 23, 0), ("press", 0.05, 1030, 21, 0),
+                                                  ("sort", 0.05, 600, 25, 0), ("mono", 0.05, 1, 14, 0), ("press", 0.0, 33, 14, 0),
+                                                  ("mono", 0.0, 257, 30, 1), ("mono", 0.0, 1500, 40, 3), ("mono", 0.0, 65536, 7, 0)])
+def test_fused_policy_rollout_kernel_shapes_agree(kind, noise, n, K, flags, pipeline):
+    """Up to 256 envs x CUs the learned-policy rollout has three kernel shapes: actor + critic + RNG waves per 64 envs
+    (by size, rollout_pipeline 0: the one the test above holds to the two-launch collector), actor + critic waves (1)
+    and one wave per 32 envs doing everything (2).  All three must collect the same bits and leave the same state -
+    also unmasked (flags 1) and with check_overflow (3), over auto-resets and with a one-step and a bootstrap-only tail."""
+    import torch
+
+    import marl_sortingenv_amd as M
+
+    kw = dict(kind=kind, num_envs=n, device=0, base_seed=29, max_steps=12, noise_sorting=noise, balesize=200)
+    a, b = M.BatchedSortingEnv(rollout_pipeline=0, **kw), M.BatchedSortingEnv(rollout_pipeline=pipeline, **kw)
+    pol = M.MlpPolicy(a.obs_dim, a.num_actions, _weights(a.obs_dim, a.num_actions, seed=37), device=0, precision="f16x3")
+    sm = (torch.arange(n) % 2).to(torch.int32).cuda() if kind == "press" else None
+    fa = M.FusedPolicyRollout(a, pol, K, seed=6, sort_mode=sm)
+    fb = M.FusedPolicyRollout(b, pol, K, seed=6, sort_mode=sm)
+    how = dict(use_action_masking=not (flags & 1), check_overflow=bool(flags & 2))
+    for it, steps in enumerate((K, K, 1, K)):
+        x, y = fa.collect(steps, **how), fb.collect(steps, **how)
+        for key in x:
+            assert torch.equal(x[key], y[key]), (it, key)  # (rows past `steps` keep the previous, equal, rollout)
+        for sa, sb in zip(a.get_state(), b.get_state()):
+            assert torch.equal(sa, sb), it
+    x, y = fa.collect(deterministic=True, **how), fb.collect(deterministic=True, **how)
+    for key in x:
+        assert torch.equal(x[key], y[key]), ("deterministic", key)
+    assert a.error_count() == 0 and b.error_count() == 0
+
+
 @pytest.mark.parametrize("n,noise", [(3000, 0.05), (70300, 0.0)])
 def test_fused_rollout_with_the_sorting_agent_in_the_loop(n, noise):
     """Env_2_Pressing with its pre-trained sorting agent (env_2_press.py:101-104) as a second network inside the

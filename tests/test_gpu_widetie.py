@@ -57,10 +57,12 @@ def test_wide_window_rollout_kernels_equal_shipped_literal(kind, pipeline):
     assert a.error_count() == 0
 
 
-@pytest.mark.parametrize("kind,n", [("mono", 3000), ("press", 70300)])
-def test_wide_window_fused_policy_rollout_equals_shipped(kind, n):
+@pytest.mark.parametrize("kind,n,pipeline", [("mono", 3000, 0), ("mono", 3000, 1), ("mono", 3000, 2), ("sort", 700, 0),
+                                             ("press", 70300, 0)])
+def test_wide_window_fused_policy_rollout_equals_shipped(kind, n, pipeline):
     """mse_rollout_policy steps the env with the windowed decision too: the wide-window build (fallback about
-    every third step, both tile shapes) must collect what the shipped build collects, bit for bit."""
+    every third step; every kernel shape: actor / critic / RNG waves with the ring's whole-step redo (0), actor / critic
+    waves (1), plain 32-env waves (2), 64-env waves above 65 536 envs) must collect what the shipped build collects."""
     import torch
 
     import marl_sortingenv_amd as M
@@ -69,7 +71,7 @@ def test_wide_window_fused_policy_rollout_equals_shipped(kind, n):
     lib = _wide_lib()
     K = 20
     kw = dict(kind=kind, num_envs=n, device=0, base_seed=23, max_steps=15, noise_sorting=0.05, balesize=200)
-    a, b = M.BatchedSortingEnv(library=lib, **kw), M.BatchedSortingEnv(**kw)
+    a, b = M.BatchedSortingEnv(library=lib, rollout_pipeline=pipeline, **kw), M.BatchedSortingEnv(**kw)
     w = _weights(a.obs_dim, a.num_actions, seed=9)
     fa = M.FusedPolicyRollout(a, M.MlpPolicy(a.obs_dim, a.num_actions, w, device=0, library=lib), K, seed=4)
     fb = M.FusedPolicyRollout(b, M.MlpPolicy(b.obs_dim, b.num_actions, w, device=0), K, seed=4)

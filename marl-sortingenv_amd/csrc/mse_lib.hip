@@ -1519,7 +1519,11 @@ __global__ __launch_bounds__(RING ? 768 : 512) void k_rollout_policy_roles(Param
             const uint32_t legal[2] = {legal_of(mb0), legal_of(mb1)};
             const uint32_t words[2] = {mse_policy_word(key0, t), mse_policy_word(key1, t)};
             msep::TileOut p[2];
+#ifdef MSE_ACTOR_PLAIN // (A/B builds: the two tiles' layers issued together, as policy_tiles does)
             msep::actor_tiles<NR, true, 2>(wl, lane, x, legal, deterministic != 0, words, p);
+#else
+            msep::actor_tiles_pipelined<NR>(wl, lane, x, legal, deterministic != 0, words, p);
+#endif
             const int a = h ? p[1].action : p[0].action; // lane l is env l: tile l >> 5, column l & 31
             const float logp = h ? p[1].logp : p[0].logp;
             MSE_TLB(e.tl, 0); // actor network and sampling

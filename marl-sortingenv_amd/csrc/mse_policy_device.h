@@ -436,6 +436,59 @@ __device__ __forceinline__ void actor_tiles(lds_f4 wl, int lane, const float (*x
     for (int t = 0; t < T; ++t) sample_tile<NR>(lg[t], h, legal[t], deterministic, word[t], nullptr, out[t]);
 }
 
+// actor_tiles for two tiles as a software pipeline: a tile's matrix products are issued between the other tile's
+// activation arithmetic (the MFMA pipe and the vector unit run side by side, and a wave issues in order: twelve MFMAs in
+// a row keep it off the vector unit for 12 x 32 cycles per layer), stage by stage
+//   M1(t0) | M1(t1) + S1(t0) | M2(t0) + S1(t1) | M2(t1) + S2(t0) | M3(t0) + S2(t1) | M3(t1) + sample(t0) | sample(t1)
+// with M = a layer's six MFMAs and S = 16 x (exp, add, rcp) + the f16 split.  sched_group_barrier asks the scheduler
+// for one MFMA per `per` vector instructions inside a stage; the arithmetic of a tile is what actor_tiles does.
+#define MSEP_INTERLEAVE_6(per)                                          \
+    do {                                                                \
+        _Pragma("unroll") for (int k_ = 0; k_ < 6; ++k_) {              \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);          \
+            __builtin_amdgcn_sched_group_barrier(0x002, per, 0);        \
+        }                                                               \
+    } while (0)
+template <int NR>
+__device__ __forceinline__ void actor_tiles_pipelined(lds_f4 wl, int lane, const float (*x)[16], const uint32_t *legal,
+                                                      bool deterministic, const uint32_t *word, TileOut *out)
+{
+    const int h = lane >> 5;
+    Operands<true, 1> op0, op1;
+    float hid[16];
+    f32x16 a0[1], a1[1], b0[1], b1[1];
+    auto activate = [&](const f32x16 &acc, Operands<true, 1> &op) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) hid[r] = sigmoid2(acc[r]);
+        op.set(0, hid);
+    };
+    op0.set(0, x[0]);
+    apply_layer<1>(wl, lane, h, 0, op0, a0);
+    __builtin_amdgcn_sched_barrier(0);
+    op1.set(0, x[1]);
+    apply_layer<1>(wl, lane, h, 0, op1, a1);
+    activate(a0[0], op0);
+    MSEP_INTERLEAVE_6(12);
+    __builtin_amdgcn_sched_barrier(0);
+    apply_layer<1>(wl, lane, h, 1, op0, b0);
+    activate(a1[0], op1);
+    MSEP_INTERLEAVE_6(12);
+    __builtin_amdgcn_sched_barrier(0);
+    apply_layer<1>(wl, lane, h, 1, op1, b1);
+    activate(b0[0], op0);
+    MSEP_INTERLEAVE_6(12);
+    __builtin_amdgcn_sched_barrier(0);
+    apply_layer<1>(wl, lane, h, 2, op0, a0);
+    activate(b1[0], op1);
+    MSEP_INTERLEAVE_6(12);
+    __builtin_amdgcn_sched_barrier(0);
+    apply_layer<1>(wl, lane, h, 2, op1, a1);
+    sample_tile<NR>(a0[0], h, legal[0], deterministic, word[0], nullptr, out[0]);
+    MSEP_INTERLEAVE_6(12);
+    __builtin_amdgcn_sched_barrier(0);
+    sample_tile<NR>(a1[0], h, legal[1], deterministic, word[1], nullptr, out[1]);
+}
+
 // The critic alone for T tiles: the bootstrap value of the state a rollout ends in.  Same layers, same bits as
 // policy_tiles (a network's operations do not depend on what runs beside them).
 template <bool F16X3, int T>

@@ -2054,6 +2054,50 @@ __device__ __forceinline__ StepResult env_observe(const Snap &sn, const Params &
     return r;
 }
 
+// The reward of env_observe alone, from what is left of a snapshot once the observation is made: the sum of the purity
+// hundredths as calculate_sorting_reward takes them (empty container -> its threshold), the amount of a press started
+// this step (0 if none), the five levels' sum and penalty classes, the overflow flag.  The same expressions in the same
+// order as env_observe (which stays the one place the single-lane kernels compute it): k_rollout_policy_roles hands these
+// few words from its actor wave to its critic wave instead of evaluating them on the step's chain.
+template <int KIND>
+__device__ __forceinline__ double env_reward(int s_sum, bool lps, int amount, int total_level, const PenaltyClass &pc,
+                                             bool overflowed, const Params &P, const Tables &tb)
+{
+    double eff_v = 0.0, bonus_v = 0.0;
+    if (KIND != 1) {
+        int nb, rem;
+        divmod_small(amount, P.balesize, P.inv_balesize, nb, rem);
+        const int dist = rem < P.balesize - rem ? rem : P.balesize - rem;
+        eff_v = tb.eff[dist];
+        bonus_v = tb.bonus[nb > 3 ? 3 : nb];
+    }
+    double tanh_v = 0.0;
+    if (KIND != 2) tanh_v = tb.tanh_s[s_sum];
+    double rp = 0.0;
+    if (KIND != 1) {
+        const double state_reward = ((double)total_level / (double)(5 * P.capacity)) * P.max_state_reward;
+        bool penalised = pc.any_cat;
+        double penalty = 0.0;
+        if (__builtin_expect(pc.any_cat || pc.any_sev || pc.any_mild, 0)) {
+            double max_pen = 0.0;
+            if (pc.any_sev) max_pen = fmin(max_pen, tb.cst[CST_PEN_SEV]);
+            if (pc.any_mild) max_pen = fmin(max_pen, tb.cst[CST_PEN_MILD]);
+            penalty = pc.any_cat ? tb.cst[CST_PEN_CAT] : max_pen;
+            penalised = pc.any_cat || max_pen < 0.0;
+        }
+        if (penalised) {
+            rp = penalty;
+        } else {
+            const double ar = lps ? eff_v + bonus_v : 0.0;
+            const double v = state_reward + ar;
+            rp = v < -1.0 ? -1.0 : (v > 1.0 ? 1.0 : v);
+        }
+    }
+    double reward = KIND == 1 ? tanh_v : (KIND == 2 ? rp : tanh_v + rp);
+    if (__builtin_expect(overflowed, 0)) reward = tb.cst[CST_OVERFLOW_PEN];
+    return reward;
+}
+
 // the snapshot of a freshly reset env (observation after an auto-reset)
 __device__ __forceinline__ void snap_of_reset(Snap &sn, const double *cst)
 {

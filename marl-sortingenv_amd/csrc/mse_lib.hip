@@ -1376,7 +1376,8 @@ struct PolRolesLayout {
     static constexpr int mword_bytes = 64 * 4;                     // action-mask bits | episode-start flag << 31
     static constexpr int mask_bytes = (64 * A + 15) / 16 * 16;     // the critic wave's staging tile of mask rows
     static constexpr int bale_bytes = 5 * 64 * 16;
-    static constexpr int pair_bytes = tile_bytes + mword_bytes + mask_bytes + bale_bytes;
+    static constexpr int rew_bytes = 3 * 64 * 4;                   // what env_reward needs of a step: u32[3][64]
+    static constexpr int pair_bytes = tile_bytes + mword_bytes + mask_bytes + bale_bytes + rew_bytes;
     static constexpr int table_offset = pair_offset + kPairs * pair_bytes; // multiple of 16
 };
 
@@ -1399,6 +1400,17 @@ __global__ __launch_bounds__(RING ? 768 : 512) void k_rollout_policy_roles(Param
     using L = PolRolesLayout<KIND, RING>;
     constexpr int D = L::D, A = L::A, NR = msep::regs_for_actions(A);
     static_assert(A < 31, "the mask word keeps bit 31 for the episode-start flag");
+    // Env_3's reward (a table look-up by the purities plus calculate_press_reward's fp64 division) leaves the actor wave's
+    // chain for the critic wave: +4.4 % at 65 536 envs.  Env_1 / Env_2, whose actor waves have less to do per step (no press
+    // rules / a 2- or 11-way head) so that the critic wave is the longer one: -4 ... 6 %, the reward stays where it was.
+    constexpr bool kRewardOnCritic = KIND == 3;
+    // The same split decides how the actor wave issues its two tiles: as a software pipeline (actor_tiles_pipelined) for
+    // Env_3, +0.4 % (+2.6 % with noise); layer by layer for Env_1 / Env_2, where the pipeline cost 3 % / 7 % (same-box A/Bs).
+#ifdef MSE_ACTOR_PLAIN // (A/B builds)
+    constexpr bool kPipelinedActor = false;
+#else
+    constexpr bool kPipelinedActor = KIND == 3;
+#endif
     uint8_t *lds = reinterpret_cast<uint8_t *>(mse_dyn_lds);
     float *lw = reinterpret_cast<float *>(lds + L::weight_offset);
     uint32_t *ltab = reinterpret_cast<uint32_t *>(lds + L::table_offset);
@@ -1413,6 +1425,7 @@ __global__ __launch_bounds__(RING ? 768 : 512) void k_rollout_policy_roles(Param
     uint32_t *lmword = reinterpret_cast<uint32_t *>(lpair + L::tile_bytes);       // [64]
     uint8_t *lmask = lpair + L::tile_bytes + L::mword_bytes;
     uint4 *lbale = reinterpret_cast<uint4 *>(lmask + L::mask_bytes);
+    uint32_t *lrew = reinterpret_cast<uint32_t *>(lmask + L::mask_bytes + L::bale_bytes);
     const long long wave_row0 = ((long long)blockIdx.x * L::kPairs + pair) * 64;
     const long long rem = P.n - wave_row0;
     const int n_valid = rem >= 64 ? 64 : (rem > 0 ? (int)rem : 0);
@@ -1487,11 +1500,35 @@ __global__ __launch_bounds__(RING ? 768 : 512) void k_rollout_policy_roles(Param
         // `taken` is read a phase early (its LDS round trip rides under the observation's arithmetic) and again only if
         // the critic wave had not got to the tile by then, which a whole actor network + env transition makes unlikely
         uint32_t taken = 0;
-        auto post_row = [&](int s) { // the state the coming action is taken from: row s of the rollout buffer
-            while (__builtin_amdgcn_readfirstlane(taken) < (uint32_t)s) { // row s - 1 is out of the tile
+        auto wait_taken = [&](int s) { // the critic wave has row s - 1 (and the reward words of step s - 2) in registers
+            while (__builtin_amdgcn_readfirstlane(taken) < (uint32_t)s) {
                 __builtin_amdgcn_s_sleep(1);
                 taken = *ltaken;
             }
+        };
+        // (kRewardOnCritic) The step's reward is not on the chain: the critic wave evaluates it (env_reward) from three words - the amount
+        // of a press started this step, the levels' sum, and {purity-hundredths sum, penalty classes, flags} - and
+        // stores the rollout buffer's reward row.
+        auto post_reward_words = [&](const Snap &sn, const int *k) {
+            int lvl[5], s_sum = 0;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                lvl[m] = sn.ct[m] + sn.cf[m];
+                if (KIND != 2) s_sum += (k[m] == 101) ? P.k_thr[m] : k[m]; // (Env_2 has no sorting reward)
+            }
+            lvl[4] = sn.ce;
+            uint32_t bits = (uint32_t)s_sum | (sn.overflowed ? 1u << 20 : 0u);
+            if (KIND != 1) { // (Env_1 has no press reward)
+                const PenaltyClass pc = classify_levels(lvl, P);
+                bits |= (pc.any_cat ? 1u << 16 : 0u) | (pc.any_sev ? 1u << 17 : 0u) | (pc.any_mild ? 1u << 18 : 0u) |
+                        (sn.lps ? 1u << 19 : 0u);
+                lrew[lane] = (uint32_t)(sn.lps ? sn.lpa : 0);
+                lrew[64 + lane] = (uint32_t)(lvl[0] + lvl[1] + lvl[2] + lvl[3] + lvl[4]);
+            }
+            lrew[128 + lane] = bits;
+        };
+        auto post_row = [&](int s) { // the state the coming action is taken from: row s of the rollout buffer
+            wait_taken(s);
             lds_f32 *row = (lds_f32 *)(uintptr_t)lrow;
 #pragma unroll
             for (int j = 0; j < D; ++j) row[j] = o[j];
@@ -1519,23 +1556,23 @@ __global__ __launch_bounds__(RING ? 768 : 512) void k_rollout_policy_roles(Param
             const uint32_t legal[2] = {legal_of(mb0), legal_of(mb1)};
             const uint32_t words[2] = {mse_policy_word(key0, t), mse_policy_word(key1, t)};
             msep::TileOut p[2];
-#ifdef MSE_ACTOR_PLAIN // (A/B builds: the two tiles' layers issued together, as policy_tiles does)
-            msep::actor_tiles<NR, true, 2>(wl, lane, x, legal, deterministic != 0, words, p);
-#else
-            msep::actor_tiles_pipelined<NR>(wl, lane, x, legal, deterministic != 0, words, p);
-#endif
+            if (kPipelinedActor) msep::actor_tiles_pipelined<NR>(wl, lane, x, legal, deterministic != 0, words, p);
+            else msep::actor_tiles<NR, true, 2>(wl, lane, x, legal, deterministic != 0, words, p);
             const int a = h ? p[1].action : p[0].action; // lane l is env l: tile l >> 5, column l & 31
             const float logp = h ? p[1].logp : p[0].logp;
             MSE_TLB(e.tl, 0); // actor network and sampling
-            StepResult r;
+            Snap sn;
             if (RING) {
-                Snap sn;
                 env_dynamics<KIND, NOISE, false>(e, ring, P, tb, a, sm, flags, bales, sn);
-                taken = *ltaken;
-                r = env_observe<KIND, NOISE>(sn, P, tb, kcur, o);
-            } else {
-                taken = *ltaken;
-                r = env_step<KIND, NOISE, false>(e, P, tb, a, sm, flags, bales, kcur, o);
+            } else { // env_step's two halves, with the lane's own generator
+                RngLocal own{e.rng};
+                env_dynamics<KIND, NOISE, false, RngLocal>(e, own, P, tb, a, sm, flags, bales, sn);
+            }
+            taken = *ltaken;
+            const StepResult r = env_observe<KIND, NOISE>(sn, P, tb, kcur, o); // (kRewardOnCritic: its reward arithmetic is dead code)
+            if (kRewardOnCritic) {
+                wait_taken(s + 1);
+                post_reward_words(sn, kcur);
             }
             if (__builtin_expect(r.done != 0, 0)) {
                 auto_reset_env(e, P, tb, bales, kcur);
@@ -1548,7 +1585,7 @@ __global__ __launch_bounds__(RING ? 768 : 512) void k_rollout_policy_roles(Param
                 const long long at = (long long)s * P.n + i;
                 if (actions_out != nullptr) __builtin_nontemporal_store(a, &actions_out[at]);
                 if (logp_out != nullptr) __builtin_nontemporal_store(logp, &logp_out[at]);
-                if (reward_out != nullptr) __builtin_nontemporal_store((float)r.reward, &reward_out[at]);
+                if (!kRewardOnCritic && reward_out != nullptr) __builtin_nontemporal_store((float)r.reward, &reward_out[at]);
             }
         }
         post_row(k_steps); // the state the rollout ends in, for the bootstrap value
@@ -1587,8 +1624,19 @@ __global__ __launch_bounds__(RING ? 768 : 512) void k_rollout_policy_roles(Param
             for (int j = 0; j < NP; ++j) piece[j] = reinterpret_cast<const float4 *>(ltile)[(lane + 64 * j) < NQ ? lane + 64 * j : 0];
         }
         mw = lmword[lane];
+        uint32_t rw[3] = {0u, 0u, 0u};
+        if (kRewardOnCritic && s > 0) { // the reward words of step s - 1, posted before this barrier
+#pragma unroll
+            for (int w = 0; w < 3; ++w) rw[w] = lrew[w * 64 + lane];
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the reads have returned
         if (lane == 0) *ltaken = (uint32_t)(s + 1);
+        if (kRewardOnCritic && s > 0 && live && reward_out != nullptr) {
+            const PenaltyClass pc{(rw[2] & (1u << 16)) != 0, (rw[2] & (1u << 17)) != 0, (rw[2] & (1u << 18)) != 0};
+            const double rew = env_reward<KIND>((int)(rw[2] & 0xFFFFu), (rw[2] & (1u << 19)) != 0, (int)rw[0], (int)rw[1], pc,
+                                                (rw[2] & (1u << 20)) != 0, P, tb);
+            __builtin_nontemporal_store((float)rew, &reward_out[(long long)(s - 1) * P.n + i]);
+        }
     };
 #ifdef MSE_TIMELINE
     Timeline ctl;
@@ -1632,12 +1680,14 @@ __global__ __launch_bounds__(RING ? 768 : 512) void k_rollout_policy_roles(Param
     ctl.flush(1);
 #endif
     lds_barrier_all();
-    if (last_value_out != nullptr) {
+    {
         float x[2][16], v[2];
         uint32_t mw;
-        take_tile(k_steps, x, nullptr, mw);
-        msep::value_tiles<true, 2>(wl, lane, x, v);
-        if (live) last_value_out[i] = h ? v[1] : v[0];
+        take_tile(k_steps, x, nullptr, mw); // (and the last step's reward row)
+        if (last_value_out != nullptr) {
+            msep::value_tiles<true, 2>(wl, lane, x, v);
+            if (live) last_value_out[i] = h ? v[1] : v[0];
+        }
     }
 }
 

@@ -1401,11 +1401,11 @@ __global__ __launch_bounds__(RING ? 768 : 512) void k_rollout_policy_roles(Param
     constexpr int D = L::D, A = L::A, NR = msep::regs_for_actions(A);
     static_assert(A < 31, "the mask word keeps bit 31 for the episode-start flag");
     // Env_3's reward (a table look-up by the purities plus calculate_press_reward's fp64 division) leaves the actor wave's
-    // chain for the critic wave: +4.4 % at 65 536 envs.  Env_1 / Env_2, whose actor waves have less to do per step (no press
-    // rules / a 2- or 11-way head) so that the critic wave is the longer one: -4 ... 6 %, the reward stays where it was.
+    // chain for the critic wave: +4.4 % at 65 536 envs.  Env_2 (the division alone): +-0.5 %; Env_1 (one look-up): -1.3 %;
+    // they keep it where it was.
     constexpr bool kRewardOnCritic = KIND == 3;
-    // The same split decides how the actor wave issues its two tiles: as a software pipeline (actor_tiles_pipelined) for
-    // Env_3, +0.4 % (+2.6 % with noise); layer by layer for Env_1 / Env_2, where the pipeline cost 3 % / 7 % (same-box A/Bs).
+    // How the actor wave issues its two tiles: as a software pipeline (actor_tiles_pipelined) for Env_3, +0.4 % (+2.6 % with
+    // noise); layer by layer for Env_1 / Env_2, where the pipeline cost 3 % / 7 % (same-box A/Bs, profiles/r03).
 #ifdef MSE_ACTOR_PLAIN // (A/B builds)
     constexpr bool kPipelinedActor = false;
 #else

@@ -1470,6 +1470,42 @@ struct BaleRefCompact {
     }
 };
 
+// The ledger kept by ANOTHER wave (k_rollout_policy_roles: the critic wave): the lane that steps the env only notes
+// what a step books - at most two press_bale calls, in the reference's order, and the auto-reset's clear after them -
+// and hands the note over; the other wave replays it on the real ledger (replay()).  q100 < 128 (bale_quality_int).
+struct BaleNote {
+    uint32_t *head; // calls (2 bits) | clear << 2 | m_0 << 3 | m_1 << 6 | q100_0 << 9 | q100_1 << 16
+    uint32_t *n;    // n[0], n[1]: the amounts
+    __device__ __forceinline__ void begin_step() const
+    {
+        *head = 0u;
+        n[0] = n[1] = 0u;
+    }
+    template <class BALES>
+    static __device__ __forceinline__ void replay(uint32_t head, uint32_t n0, uint32_t n1, const BALES &ledger, const Params &P,
+                                                  const int *ptab);
+};
+template <>
+__device__ __forceinline__ void press_bale<BaleNote>(const BaleNote &note, int m, const Params &P, const int *ptab, int n, int q100)
+{
+    const uint32_t h = *note.head, second = h & 3u; // 0 | 1 calls so far
+    *note.head = (h + 1u) | ((uint32_t)m << (second ? 6 : 3)) | ((uint32_t)q100 << (second ? 16 : 9));
+    note.n[0] = second ? note.n[0] : (uint32_t)n;
+    note.n[1] = second ? (uint32_t)n : note.n[1];
+}
+template <class BALES>
+__device__ __forceinline__ void BaleNote::replay(uint32_t head, uint32_t n0, uint32_t n1, const BALES &ledger, const Params &P,
+                                                 const int *ptab)
+{
+    const uint32_t calls = head & 3u;
+    if (calls > 0u) press_bale(ledger, (int)((head >> 3) & 7u), P, ptab, (int)n0, (int)((head >> 9) & 127u));
+    if (__builtin_expect(calls > 1u, 0)) press_bale(ledger, (int)((head >> 6) & 7u), P, ptab, (int)n1, (int)((head >> 16) & 127u));
+    if (__builtin_expect((head & 4u) != 0u, 0)) {
+#pragma unroll
+        for (int m = 0; m < 5; ++m) ledger.store(m, make_uint4(0, 0, 0, 0));
+    }
+}
+
 // env_super.py:626-640 press_action_rules = check_press_status (:642-659) then use_press (:722-769)
 template <bool TRACE = false, class BALES = BaleRef>
 __device__ __forceinline__ void press_action_rules(Env &e, const Params &P, const int *ptab, int press_action, const BALES &bales,
@@ -1763,6 +1799,11 @@ __device__ __forceinline__ void clear_bales(const BALES &bales)
 {
 #pragma unroll
     for (int m = 0; m < 5; ++m) bales.store(m, make_uint4(0, 0, 0, 0));
+}
+template <>
+__device__ __forceinline__ void clear_bales<BaleNote>(const BaleNote &note)
+{
+    *note.head |= 4u;
 }
 
 

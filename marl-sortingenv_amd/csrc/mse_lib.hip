@@ -1377,7 +1377,8 @@ struct PolRolesLayout {
     static constexpr int mask_bytes = (64 * A + 15) / 16 * 16;     // the critic wave's staging tile of mask rows
     static constexpr int bale_bytes = 5 * 64 * 16;
     static constexpr int rew_bytes = 3 * 64 * 4;                   // what env_reward needs of a step: u32[3][64]
-    static constexpr int pair_bytes = tile_bytes + mword_bytes + mask_bytes + bale_bytes + rew_bytes;
+    static constexpr int note_bytes = 3 * 64 * 4;                  // the step's bale bookings (BaleNote): u32[3][64]
+    static constexpr int pair_bytes = tile_bytes + mword_bytes + mask_bytes + bale_bytes + rew_bytes + note_bytes;
     static constexpr int table_offset = pair_offset + kPairs * pair_bytes; // multiple of 16
 };
 
@@ -1426,6 +1427,7 @@ __global__ __launch_bounds__(RING ? 768 : 512) void k_rollout_policy_roles(Param
     uint8_t *lmask = lpair + L::tile_bytes + L::mword_bytes;
     uint4 *lbale = reinterpret_cast<uint4 *>(lmask + L::mask_bytes);
     uint32_t *lrew = reinterpret_cast<uint32_t *>(lmask + L::mask_bytes + L::bale_bytes);
+    uint32_t *lnote = lrew + L::rew_bytes / 4;
     const long long wave_row0 = ((long long)blockIdx.x * L::kPairs + pair) * 64;
     const long long rem = P.n - wave_row0;
     const int n_valid = rem >= 64 ? 64 : (rem > 0 ? (int)rem : 0);
@@ -1449,11 +1451,11 @@ __global__ __launch_bounds__(RING ? 768 : 512) void k_rollout_policy_roles(Param
     const BaleRef bales{lbale + lane, 64};
     Env e;
     int sm = -1;
-    if (role == 0) {
-        if (P.track_bales && pair_active) {
+    if (role == 1 && P.track_bales && pair_active) { // the bale ledger lives with the critic wave (BaleNote)
 #pragma unroll
-            for (int m = 0; m < 5; ++m) lbale[m * 64 + lane] = planes[(long long)(PL_BALE0 + m) * P.n_pad + i];
-        }
+        for (int m = 0; m < 5; ++m) lbale[m * 64 + lane] = planes[(long long)(PL_BALE0 + m) * P.n_pad + i];
+    }
+    if (role == 0) {
         load_env<KIND, NOISE>(e, planes, P, i);
         if (KIND == 2 && sort_mode != nullptr) sm = sort_mode[i];
         if (lane == 0) *ltaken = 0u;
@@ -1506,6 +1508,9 @@ __global__ __launch_bounds__(RING ? 768 : 512) void k_rollout_policy_roles(Param
                 taken = *ltaken;
             }
         };
+        // The bale ledger is output-only state: the step notes its bookings (BaleNote) and the critic wave replays them
+        uint32_t note_head = 0u, note_n[2] = {0u, 0u};
+        const BaleNote note{&note_head, note_n};
         // (kRewardOnCritic) The step's reward is not on the chain: the critic wave evaluates it (env_reward) from three words - the amount
         // of a press started this step, the levels' sum, and {purity-hundredths sum, penalty classes, flags} - and
         // stores the rollout buffer's reward row.
@@ -1562,21 +1567,25 @@ __global__ __launch_bounds__(RING ? 768 : 512) void k_rollout_policy_roles(Param
             const float logp = h ? p[1].logp : p[0].logp;
             MSE_TLB(e.tl, 0); // actor network and sampling
             Snap sn;
+            note.begin_step();
             if (RING) {
-                env_dynamics<KIND, NOISE, false>(e, ring, P, tb, a, sm, flags, bales, sn);
+                env_dynamics<KIND, NOISE, false, RngRing, false, false, BaleNote>(e, ring, P, tb, a, sm, flags, note, sn);
             } else { // env_step's two halves, with the lane's own generator
                 RngLocal own{e.rng};
-                env_dynamics<KIND, NOISE, false, RngLocal>(e, own, P, tb, a, sm, flags, bales, sn);
+                env_dynamics<KIND, NOISE, false, RngLocal, false, false, BaleNote>(e, own, P, tb, a, sm, flags, note, sn);
             }
             taken = *ltaken;
             const StepResult r = env_observe<KIND, NOISE>(sn, P, tb, kcur, o); // (kRewardOnCritic: its reward arithmetic is dead code)
-            if (kRewardOnCritic) {
-                wait_taken(s + 1);
-                post_reward_words(sn, kcur);
-            }
+            if (kRewardOnCritic || P.track_bales) wait_taken(s + 1); // the words of step s - 1 are in the critic wave's registers
+            if (kRewardOnCritic) post_reward_words(sn, kcur);         // (before the auto-reset overwrites the purities)
             if (__builtin_expect(r.done != 0, 0)) {
-                auto_reset_env(e, P, tb, bales, kcur);
+                auto_reset_env<false, BaleNote>(e, P, tb, note, kcur);
                 env_obs<KIND>(e, P, tb, kcur, o);
+            }
+            if (P.track_bales) {
+                lnote[lane] = note_head;
+                lnote[64 + lane] = note_n[0];
+                lnote[128 + lane] = note_n[1];
             }
             mbits = action_mask_bits<KIND>(e, P);
             last_done = r.done;
@@ -1596,10 +1605,6 @@ __global__ __launch_bounds__(RING ? 768 : 512) void k_rollout_policy_roles(Param
         if (live && last_done_out != nullptr) last_done_out[i] = (uint8_t)last_done;
         // (RING: the generator state is written by the RNG lane, which steps back to the consumed position)
         if (live) store_env<KIND, NOISE>(e, planes, P, i, false, /*write_rng_state=*/!RING);
-        if (P.track_bales && live) {
-#pragma unroll
-            for (int m = 0; m < 5; ++m) planes[(long long)(PL_BALE0 + m) * P.n_pad + i] = lbale[m * 64 + lane];
-        }
         return;
     }
 
@@ -1624,13 +1629,18 @@ __global__ __launch_bounds__(RING ? 768 : 512) void k_rollout_policy_roles(Param
             for (int j = 0; j < NP; ++j) piece[j] = reinterpret_cast<const float4 *>(ltile)[(lane + 64 * j) < NQ ? lane + 64 * j : 0];
         }
         mw = lmword[lane];
-        uint32_t rw[3] = {0u, 0u, 0u};
+        uint32_t rw[3] = {0u, 0u, 0u}, nw[3] = {0u, 0u, 0u};
         if (kRewardOnCritic && s > 0) { // the reward words of step s - 1, posted before this barrier
 #pragma unroll
             for (int w = 0; w < 3; ++w) rw[w] = lrew[w * 64 + lane];
         }
+        if (P.track_bales && s > 0) { // ... and its bale bookings
+#pragma unroll
+            for (int w = 0; w < 3; ++w) nw[w] = lnote[w * 64 + lane];
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the reads have returned
         if (lane == 0) *ltaken = (uint32_t)(s + 1);
+        if (P.track_bales && s > 0) BaleNote::replay(nw[0], nw[1], nw[2], bales, P, tb.press_time);
         if (kRewardOnCritic && s > 0 && live && reward_out != nullptr) {
             const PenaltyClass pc{(rw[2] & (1u << 16)) != 0, (rw[2] & (1u << 17)) != 0, (rw[2] & (1u << 18)) != 0};
             const double rew = env_reward<KIND>((int)(rw[2] & 0xFFFFu), (rw[2] & (1u << 19)) != 0, (int)rw[0], (int)rw[1], pc,
@@ -1683,7 +1693,11 @@ __global__ __launch_bounds__(RING ? 768 : 512) void k_rollout_policy_roles(Param
     {
         float x[2][16], v[2];
         uint32_t mw;
-        take_tile(k_steps, x, nullptr, mw); // (and the last step's reward row)
+        take_tile(k_steps, x, nullptr, mw); // (and the last step's reward row and bale bookings)
+        if (P.track_bales && live) {
+#pragma unroll
+            for (int m = 0; m < 5; ++m) planes[(long long)(PL_BALE0 + m) * P.n_pad + i] = lbale[m * 64 + lane];
+        }
         if (last_value_out != nullptr) {
             msep::value_tiles<true, 2>(wl, lane, x, v);
             if (live) last_value_out[i] = h ? v[1] : v[0];

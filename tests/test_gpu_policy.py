@@ -287,6 +287,25 @@ def test_fused_policy_rollout_kernel_shapes_agree(kind, noise, n, K, flags, pipe
     assert a.error_count() == 0 and b.error_count() == 0
 
 
+@pytest.mark.parametrize("kind", ["mono", "sort"])
+def test_fused_policy_rollout_kernel_shapes_agree_without_bale_tracking(kind):
+    """track_bales=False: the roles kernel posts no bale bookings (and, for Env_1, nothing at all besides the rows)."""
+    import torch
+
+    import marl_sortingenv_amd as M
+
+    kw = dict(kind=kind, num_envs=700, device=0, base_seed=41, max_steps=9, noise_sorting=0.05, balesize=200, track_bales=False)
+    a, b = M.BatchedSortingEnv(rollout_pipeline=0, **kw), M.BatchedSortingEnv(rollout_pipeline=2, **kw)
+    pol = M.MlpPolicy(a.obs_dim, a.num_actions, _weights(a.obs_dim, a.num_actions, seed=38), device=0, precision="f16x3")
+    fa, fb = M.FusedPolicyRollout(a, pol, 20, seed=6), M.FusedPolicyRollout(b, pol, 20, seed=6)
+    for it in range(2):
+        x, y = fa.collect(), fb.collect()
+        for key in x:
+            assert torch.equal(x[key], y[key]), (it, key)
+        for sa, sb in zip(a.get_state(), b.get_state()):
+            assert torch.equal(sa, sb), it
+
+
 @pytest.mark.parametrize("n,noise", [(3000, 0.05), (70300, 0.0)])
 def test_fused_rollout_with_the_sorting_agent_in_the_loop(n, noise):
     """Env_2_Pressing with its pre-trained sorting agent (env_2_press.py:101-104) as a second network inside the
